@@ -1,0 +1,158 @@
+/* libvqa_hip.so -- C ABI of the MI355X (gfx950) kernels behind the VQA
+ * attention / fusion / classifier train step.
+ *
+ * The reference (SanyamSaxena/vqa) is pure PyTorch and has no FFI; every entry
+ * point below replaces the stock-PyTorch op sequence cited beside it (paths
+ * relative to the reference checkout).  The host binds them with ctypes.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller; nothing here
+ *     allocates, frees or synchronises; work is enqueued on `stream`;
+ *   - return 0 on success, a negative code otherwise (-22: bad argument, the
+ *     text is available from vqa_last_error_string(); <= -1000: HIP launch
+ *     error -(hipError_t) - 1000);
+ *   - dtype: VQA_F32 (0) or VQA_BF16 (1) is the STORAGE type of activations and
+ *     weights; arithmetic is fp32 (bf16 MFMA products accumulate in fp32);
+ *   - matrices are row-major with an explicit leading dimension (elements).
+ *     Feature dimensions and leading dimensions of `dtype` matrices are
+ *     multiples of 8 elements (16-byte chunks); callers zero-pad.
+ *   - dropout is a counter-based hash of (seed, logical element index):
+ *     keep iff murmur3_fmix32(index * 0x9E3779B1 + seed) >= p * 2^32, kept
+ *     values scaled by 1/(1-p); p == 0 disables it.
+ */
+#ifndef VQA_HIP_H
+#define VQA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifndef __HIP__
+typedef struct ihipStream_t* hipStream_t;
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VQA_HIP_VERSION 100
+#define VQA_F32 0
+#define VQA_BF16 1
+
+int vqa_version(void);
+const char* vqa_last_error_string(void);
+
+/* ---- question encoder ---------------------------------------------------- */
+
+/* len[b] = L - #(tokens[b,:] == 0).                seq2vec.py:11-14 (process_lengths) */
+int vqa_process_lengths(const int64_t* tokens, int32_t* lengths, int B, int L, hipStream_t stream);
+
+/* out[row(b,t), 0:width] = table[tokens[b,t], 0:width]; row = t*B+b when time_major
+ * else b*L+t.  Ids outside [0, n_rows) read row 0 (the pad row).
+ *                                                   seq2vec.py:35-37, 42 (nn.Embedding) */
+int vqa_embedding_gather(const int64_t* tokens, const void* table, void* out, int B, int L, int width,
+                         int ld_table, int ld_out, int n_rows, int time_major, int dtype, hipStream_t stream);
+
+/* One LSTM step after the recurrent product: gates = sum_s slabs[s] + xg_t (xg_t holds
+ * x_t W_ih^T + b_ih + b_hh), gate order i,f,g,o; updates c (fp32) and h; rows whose last
+ * valid token is step t (len-1, or L-1 for an all-pad row) also write q.
+ *                                  seq2vec.py:38, 43 (nn.LSTM) and 16-25 (select_last) */
+int vqa_lstm_cell(const float* slabs, int nslab, size_t slab_stride, const void* xg_t, int ld_xg, float* c,
+                  void* h, int ld_h, const int32_t* lengths, float* q_f32, void* q_t, int ld_q,
+                  int B, int H, int t, int L, int dtype, hipStream_t stream);
+
+/* out[b, col0:col0+Ec] = l2norm(sum_t table[cap[b,t]] * (cap != 0) / max(#nonzero, 1e-9))
+ *                      model.py:1571-1574 (mean_pooling), 1678 (F.normalize), 1734 (cat) */
+int vqa_caption_pool(const int64_t* cap_tokens, const void* table, void* out, int B, int Tc, int Ec,
+                     int ld_table, int n_rows, int ld_out, int col0, int dtype, hipStream_t stream);
+
+/* ---- image side ------------------------------------------------------------ */
+
+/* inv_norm[row] = 1 / max(||V[row,:]||_2, 1e-12)     model.py:1678 (F.normalize semantics) */
+int vqa_inv_norm(const void* V, float* inv_norm, long rows, int Dv, int ldV, int dtype, hipStream_t stream);
+
+/* Fused attention over the region grid, one workgroup per sample:
+ *   s_r = w_a . tanh(P[b,r,:] + qa[b,:]) + c;  p = softmax_r(s);
+ *   pooled[b,:] = sum_r p_r inv_norm[b,r] V[b,r,:].
+ * No reference counterpart (the reference pools with torch.mean, model.py:161-164,
+ * which this reduces to for w_a = 0). */
+size_t vqa_attn_lds_bytes(int R, int A, int Dv);
+int vqa_attn_fwd(const void* P, int ldP, const void* V, int ldV, const float* qa, int ld_qa, const float* w_a,
+                 const float* c_a, const float* inv_norm, float* p_out, void* pooled_t, float* pooled_f32,
+                 int ld_pool, int B, int R, int A, int Dv, int dtype, hipStream_t stream);
+/* Backward of the above: dP is written pre-multiplied by inv_norm (so dW_va = dP^T V),
+ * dqa[b,:] = sum_r dP_unscaled, dwa_part[b,:] and dc_part[b] are per-sample partials. */
+int vqa_attn_bwd(const void* P, int ldP, const void* V, int ldV, const float* qa, int ld_qa, const float* w_a,
+                 const float* inv_norm, const float* p_in, const float* d_pooled, int ld_dpool, void* dP, int ld_dP,
+                 float* dqa_f32, void* dqa_t, int ld_dqa, float* dwa_part, float* dc_part, int B, int R, int A, int Dv,
+                 int dtype, hipStream_t stream);
+
+/* ---- GEMM:  C[M,N] = sum_k A(m,k) B(n,k) ------------------------------------
+ * a_kmajor / b_kmajor: 1 when the operand is stored with k contiguous ([M][K], [N][K] as an
+ * nn.Linear weight), 0 when stored [K][M] / [K][N].  engine: 0 = MFMA for bf16 (fp32 always
+ * runs the VALU kernel), 1 = force the VALU kernel (cross-check).
+ *                   nn.Linear forward / backward: model.py:44, 55-58, 63, 68, 74, 77 */
+int vqa_gemm_splitk_hint(int M, int N, int K);
+/* fp32 partial sums: slabs[s][m][n], s < splitk (consumers sum the slabs) */
+int vqa_gemm_slabs(const void* A, int lda, int a_kmajor, const void* B, int ldb, int b_kmajor, float* slabs,
+                   size_t slab_stride, int ld_slab, int M, int N, int K, int splitk, int dtype, int engine,
+                   hipStream_t stream);
+/* C = act(row_scale[m] * (A B^T) + bias[n]); act 0 none, 1 tanh; bias / row_scale may be NULL */
+int vqa_gemm_fused(const void* A, int lda, int a_kmajor, const void* B, int ldb, int b_kmajor, void* C, int ldc,
+                   int M, int N, int K, const float* bias, const float* row_scale, int act, int out_dtype,
+                   int dtype, int engine, hipStream_t stream);
+
+/* ---- split-K reduce + epilogues of the head ------------------------------------ */
+
+/* v = act(row_scale[m] * sum_s slabs[s][m][n] + bias[n] + addend[m][n]);
+ * out_pre (fp32) = v; out_post (post_dtype) = dropout(v).  Either output may be NULL. */
+int vqa_epilogue(const float* slabs, int nslab, size_t slab_stride, int M, int N, const float* bias,
+                 const float* row_scale, const float* addend, int ld_add, int act, float* out_pre, int ld_pre,
+                 void* out_post, int ld_post, int post_dtype, unsigned drop_seed, float drop_p, hipStream_t stream);
+
+/* y = dropout(x)                                        model.py:38-40, 62, 67 (nn.Dropout) */
+int vqa_dropout(const void* x, int ldx, void* y, int ldy, int M, int N, unsigned seed, float p, int dtype,
+                hipStream_t stream);
+
+/* x = dropout(tanh(xv * xq))                                              model.py:71-73 */
+int vqa_fusion_fwd(const float* xv, const float* xq, void* x, int ldx, int B, int F, unsigned seed, float p,
+                   int dtype, hipStream_t stream);
+/* backward of the above down to the pre-activations of linear_v / linear_q (xv, xq are
+ * the stored tanh outputs): dzv = dx drop (1-t^2) xq (1-xv^2), dzq likewise */
+int vqa_fusion_bwd(const float* slabs, int nslab, size_t slab_stride, int ldslab, const float* xv, const float* xq,
+                   void* dzv, void* dzq, int ldz, int B, int F, unsigned seed, float p, int dtype, hipStream_t stream);
+/* backward through y = dropout(tanh(z)):  dz = (sum_s slabs) * drop * (1 - t^2), t = tanh(z)
+ *                                                                         model.py:75-76 */
+int vqa_tanh_dropout_bwd(const float* slabs, int nslab, size_t slab_stride, const float* t_pre, int ld_t, void* dz,
+                         int ldz, int M, int N, unsigned seed, float p, int dtype, hipStream_t stream);
+
+/* out[n] = sum_m X[m,n] (bias gradients), fixed summation order */
+int vqa_colsum(const void* X, int ld, float* out, int M, int N, int dtype, hipStream_t stream);
+/* dst[m,0:N] = (dtype) src[m,0:N]; dst[m,N:ld_dst] = 0 */
+int vqa_cast_pad(const float* src, int ld_src, void* dst, int ld_dst, int M, int N, int dtype, hipStream_t stream);
+
+/* ---- loss, prediction, optimiser ------------------------------------------------- */
+
+/* loss_rows[b] = logsumexp(z_b) - z_b[y_b]; dlogits = (softmax(z_b) - onehot) * grad_scale
+ * (columns C..ld_d-1 of dlogits are zeroed); dlogits may be NULL.
+ *                             train.py:35, 201 (CrossEntropyLoss) and 203 (backward) */
+int vqa_softmax_ce(const float* logits, int ld, const int64_t* target, float* loss_rows, void* dlogits, int ld_d,
+                   int B, int C, float grad_scale, int dtype, hipStream_t stream);
+/* out[0] = scale * sum(x[0:n]) in a fixed order (mean reduction of the loss) */
+int vqa_sum_scale(const float* x, float* out, int n, float scale, hipStream_t stream);
+
+/* pred[b] = first index of the row maximum (a NaN counts as the maximum, as np.argmax);
+ * when answers, type_ids and counters are given: counters[t]++ and
+ * counters[n_types + t] += (answers[b] == pred[b]).          train.py:105-110, test.py:85-90 */
+int vqa_argmax_accuracy(const float* logits, int ld, int B, int C, const int64_t* answers, const int32_t* type_ids,
+                        int n_types, int64_t* pred, uint64_t* counters, hipStream_t stream);
+
+/* Adam on flat fp32 buffers (torch.optim.Adam defaults: no weight decay, no amsgrad);
+ * grad is multiplied by grad_scale first; shadow_bf16 (optional) receives bf16(param).
+ *                                                                   train.py:34, 204 */
+int vqa_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* shadow_bf16, long n,
+                  float lr, float beta1, float beta2, float eps, int step, float grad_scale, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VQA_HIP_H */

@@ -1,0 +1,242 @@
+"""GPU parity: the HIP module (through the C ABI) against the CPU oracle.
+
+Tolerances (relative to the largest magnitude of the oracle tensor):
+fp32 storage 1e-5, bf16 storage 1e-2 -- the bars the north-star states for the
+logits; gradients are held to the same bars scaled by 2 (they chain more ops).
+Integer results (gather, lengths, argmax, counts) must be bit-exact.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vqa_ref
+
+pytestmark = pytest.mark.gpu
+
+TINY = dict(vq=30, C=11, E=12, Hq=24, Dv=32, A=16, F=16, Hf=8)
+MID = dict(vq=500, C=101, E=44, Hq=200, Dv=256, A=136, F=104, Hf=72)
+
+
+def rel_err(got: torch.Tensor, ref: torch.Tensor) -> float:
+    got = got.detach().double().cpu()
+    ref = ref.detach().double().cpu()
+    return float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+
+
+def build(kw, hops=1, cap=False, dtype=torch.float32, seed=3, drop=0.5):
+    from vqa_amd.model import VQAAttnModel
+    kw = dict(kw)
+    vc, Ec = (20, 8) if cap else (0, 0)
+    p = vqa_ref.init_params(hops=hops, seed=seed, vc=vc, Ec=Ec, **kw)
+    m = VQAAttnModel(['w'] * kw['vq'], ['a'] * kw['C'], None, dtype=dtype, emb_size=kw['E'], question_out=kw['Hq'],
+                     visual_out=kw['Dv'], attention_dim=kw['A'], fusion_in=kw['F'], fusion_hidden=kw['Hf'],
+                     hops=hops, dropout=drop, caption_vocab=vc, caption_dim=Ec if cap else 384, seed=1234)
+    m.load_state_dict(p)
+    return m.to('cuda'), p
+
+
+def batch(kw, B, R, L, seed=5, cap=False):
+    b = vqa_ref.synthetic_batch(B, R, kw['Dv'], L, kw['vq'], kw['C'], seed=seed, Tc=6 if cap else 0, vc=20 if cap else 0)
+    if B > 3:
+        b['tokens'][3] = 0          # all-pad question row
+    return b
+
+
+def oracle_params_as(p, dtype):
+    """The oracle sees the weights the kernels see: bf16 mode rounds weights (and inputs) to bf16."""
+    if dtype == torch.float32:
+        return p
+    return {k: v.to(torch.bfloat16).float() for k, v in p.items()}
+
+
+@pytest.mark.parametrize('kw,hops,cap,B,R,L', [
+    (TINY, 1, False, 4, 9, 7), (TINY, 2, False, 4, 9, 7), (TINY, 1, True, 4, 9, 7),
+    (MID, 1, False, 37, 49, 14), (MID, 2, True, 16, 196, 14),
+])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_forward_backward_eval(kw, hops, cap, B, R, L, dtype):
+    m, p = build(kw, hops, cap, dtype)
+    m.eval()
+    b = batch(kw, B, R, L, cap=cap)
+    feats = b['feats'].to(dtype)
+    po = oracle_params_as(p, dtype)
+    logits_ref, loss_ref, grads_ref = vqa_ref.loss_and_grads(po, feats.float(), b['tokens'], b['answers'],
+                                                             b.get('captions'), hops)
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    dev = 'cuda'
+    cap_t = b['captions'].to(dev) if cap else None
+    logits = m(feats.to(dev), b['tokens'].to(dev), cap_t)
+    assert logits.shape == (B, kw['C'])
+    assert rel_err(logits, logits_ref) <= tol
+    loss = torch.nn.functional.cross_entropy(logits.float(), b['answers'].to(dev))
+    loss.backward()
+    assert abs(float(loss) - float(loss_ref)) <= tol * max(1.0, abs(float(loss_ref)))
+    named = dict(m.named_parameters())
+    for k, gref in grads_ref.items():
+        g = named[k].grad
+        assert g is not None, k
+        if k.endswith('linear_a.bias'):
+            # the score offset cancels in the softmax: its gradient is rounding noise around zero
+            wref = grads_ref[k.replace('.bias', '.weight')].abs().max()
+            assert float((g.cpu() - gref).abs().max()) <= 2 * tol * max(float(wref), 1e-3), k
+            continue
+        assert rel_err(g, gref) <= 2 * tol, (k, rel_err(g, gref))
+    for k, v in named.items():
+        if k.startswith('seq2vec.') or k.startswith('caption_embedding.'):
+            assert v.grad is None and not v.requires_grad
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_golden_fixture_h1(golden_dir, dtype):
+    """Committed fixture (oracle-generated): parameters, inputs, logits, loss, every gradient, with and
+    without dropout."""
+    from vqa_amd.model import VQAAttnModel
+    z = np.load(os.path.join(golden_dir, 'g3_model_h1.npz'))
+    p = {k[6:]: torch.from_numpy(z[k]) for k in z.files if k.startswith('param:')}
+    kw = TINY
+    m = VQAAttnModel(['w'] * kw['vq'], ['a'] * kw['C'], None, dtype=dtype, emb_size=kw['E'], question_out=kw['Hq'],
+                     visual_out=kw['Dv'], attention_dim=kw['A'], fusion_in=kw['F'], fusion_hidden=kw['Hf'], seed=1234)
+    m.load_state_dict(p)
+    m = m.to('cuda')
+    tol = 1e-5 if dtype == torch.float32 else 2e-2      # fixture is fp32 arithmetic on fp32 weights
+    feats = torch.from_numpy(z['in:feats']).to('cuda')
+    tok = torch.from_numpy(z['in:tokens']).to('cuda')
+    ans = torch.from_numpy(z['in:answers']).to('cuda')
+    m.eval()
+    logits = m(feats, tok)
+    assert rel_err(logits, torch.from_numpy(z['logits'])) <= tol
+    # training mode: the dropout mask is an integer hash, the oracle draws the same one
+    m.train()
+    m.drop_step = 6                                       # next forward is dropout step 7, as in the fixture
+    logits_d = m(feats, tok)
+    assert [int(s) for s in z['drop_seeds']] == [vqa_ref.site_seed(1234, 7, s) for s in range(4)]
+    assert rel_err(logits_d, torch.from_numpy(z['logits_drop'])) <= tol
+    torch.nn.functional.cross_entropy(logits_d.float(), ans).backward()
+    named = dict(m.named_parameters())
+    for k in z.files:
+        if k.startswith('grad_drop:'):
+            gref = torch.from_numpy(z[k])
+            if k.endswith('linear_a.bias'):
+                continue
+            assert rel_err(named[k[10:]].grad, gref) <= 2 * tol, k
+
+
+def test_uniform_attention_is_mean_pooling():
+    """w_a = 0 => p = 1/R and pooled = mean over regions of the normalised features
+    (the reference's torch.mean(x, axis=(2,3)), model.py:161-164)."""
+    m, p = build(TINY, dtype=torch.float32)
+    m.eval()
+    with torch.no_grad():
+        m.attention[0].linear_a.weight.zero_()
+    b = batch(TINY, 4, 9, 7)
+    m(b['feats'].cuda(), b['tokens'].cuda())
+    ws = m._ctx[0]
+    torch.cuda.synchronize()
+    assert torch.allclose(ws['p0'].cpu(), torch.full((4, 9), 1.0 / 9), atol=1e-7)
+    ref = vqa_ref.l2_normalise(b['feats']).mean(1)
+    assert rel_err(ws['pooled0'].float(), ref) <= 1e-6
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_question_encoder_against_reference_fixture(golden_dir, dtype):
+    """Embedding gather (bit-exact), lengths (bit-exact), LSTM hidden states and last-step selection against
+    outputs of the reference's own seq2vec.LSTM sub-modules (fixture g2)."""
+    from vqa_amd.model import VQAAttnModel
+    from vqa_amd import _lib
+    z = np.load(os.path.join(golden_dir, 'g2_seq2vec.npz'))
+    E, H = z['embedding'].shape[1], z['w_hh'].shape[1]
+    m = VQAAttnModel(['w'] * (z['embedding'].shape[0] - 1), ['a'] * 5, None, dtype=dtype, emb_size=E, question_out=H,
+                     visual_out=32, attention_dim=16, fusion_in=16, fusion_hidden=8)
+    sd = m.state_dict()
+    sd['seq2vec.embedding.weight'] = torch.from_numpy(z['embedding'])
+    sd['seq2vec.rnn.weight_ih_l0'] = torch.from_numpy(z['w_ih'])
+    sd['seq2vec.rnn.weight_hh_l0'] = torch.from_numpy(z['w_hh'])
+    sd['seq2vec.rnn.bias_ih_l0'] = torch.from_numpy(z['b_ih'])
+    sd['seq2vec.rnn.bias_hh_l0'] = torch.from_numpy(z['b_hh'])
+    m.load_state_dict(sd)
+    m = m.to('cuda')
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    for name in ('main', 'rand'):
+        ids = torch.from_numpy(z[f'{name}_ids']).cuda()
+        B, L = ids.shape
+        q = m.encode_question(ids)
+        ws = m._workspace(B, 1, L, 0, ids.device)
+        torch.cuda.synchronize()
+        assert np.array_equal(ws['len'].cpu().numpy(), z[f'{name}_lengths'].astype(np.int32))
+        # gather: time-major rows t*B+b, bit-exact against the table in the storage dtype
+        emb = ws['x_emb'].view(L, B, -1)[:, :, :E].permute(1, 0, 2).float().cpu()
+        table = torch.from_numpy(z['embedding']).to(dtype).float()
+        assert torch.equal(emb, table[torch.from_numpy(z[f'{name}_ids'])])
+        if dtype == torch.float32:
+            assert torch.equal(emb, torch.from_numpy(z[f'{name}_emb']))
+        assert rel_err(q, torch.from_numpy(z[f'{name}_last'])) <= tol
+
+
+def test_train_step_matches_oracle_adam():
+    """Three fused steps (fwd + CE + bwd + Adam, dropout on) against the oracle's autograd + Adam."""
+    kw, dtype = MID, torch.float32
+    m, p = build(kw, 1, False, dtype)
+    m.train()
+    po = {k: v.clone() for k, v in p.items()}
+    names = vqa_ref.trainable_names(po)
+    mom = {k: torch.zeros_like(po[k]) for k in names}
+    var = {k: torch.zeros_like(po[k]) for k in names}
+    lr = 1e-3
+    for step in range(1, 4):
+        b = batch(kw, 24, 25, 14, seed=100 + step)
+        seeds = [vqa_ref.site_seed(1234, step, s) for s in range(4)]
+        _, loss_ref, grads = vqa_ref.loss_and_grads(po, b['feats'], b['tokens'], b['answers'], None, 1, drop_seeds=seeds)
+        for k in names:
+            vqa_ref.adam_step(po[k], grads[k], mom[k], var[k], step, lr)
+        loss = m.train_step(b['feats'].cuda(), b['tokens'].cuda(), b['answers'].cuda(), lr=lr)
+        assert abs(float(loss) - float(loss_ref)) <= 1e-5 * max(1.0, abs(float(loss_ref)))
+    sd = m.state_dict()
+    for k in names:
+        assert rel_err(sd[k], po[k]) <= 2e-5, k
+
+
+def test_argmax_and_counts_bit_exact(golden_dir):
+    from vqa_amd import _lib
+    from vqa_amd._lib import call, ptr
+    z = np.load(os.path.join(golden_dir, 'g5_ce_g6_metrics.npz'))
+    for key, exp in (('logits', 'argmax'), ('logits_nan', 'argmax_nan')):
+        lg = torch.from_numpy(z[key]).cuda().contiguous()
+        B, C = lg.shape
+        pred = torch.zeros(B, dtype=torch.int64, device='cuda')
+        counters = torch.zeros(8, dtype=torch.int64, device='cuda')
+        ans = torch.from_numpy(z['target']).cuda()
+        types = torch.from_numpy(z['types'].astype(np.int32)).cuda()
+        call('vqa_argmax_accuracy', ptr(lg), C, B, C, ptr(ans), ptr(types), 4, ptr(pred), ptr(counters))
+        torch.cuda.synchronize()
+        assert np.array_equal(pred.cpu().numpy(), z[exp])
+        assert np.array_equal(pred.cpu().numpy(), np.argmax(z[key], axis=1))
+        if key == 'logits':
+            assert np.array_equal(counters.cpu().numpy()[:4], z['count'])
+            assert np.array_equal(counters.cpu().numpy()[4:], z['right'])
+    # big random case with forced ties, against numpy
+    g = torch.Generator().manual_seed(0)
+    lg = torch.randint(-3, 4, (257, 3000), generator=g).float()
+    pred = torch.zeros(257, dtype=torch.int64, device='cuda')
+    lgd = lg.cuda()
+    call('vqa_argmax_accuracy', ptr(lgd), 3000, 257, 3000, None, None, 4, ptr(pred), None)
+    torch.cuda.synchronize()
+    assert np.array_equal(pred.cpu().numpy(), np.argmax(lg.numpy(), axis=1))
+
+
+def test_softmax_ce_fixture(golden_dir):
+    from vqa_amd._lib import call, ptr, F32
+    z = np.load(os.path.join(golden_dir, 'g5_ce_g6_metrics.npz'))
+    lg = torch.from_numpy(z['logits']).cuda()
+    B, C = lg.shape
+    y = torch.from_numpy(z['target']).cuda()
+    rows = torch.zeros(B, device='cuda')
+    dl = torch.zeros(B, 16, device='cuda')
+    out = torch.zeros(1, device='cuda')
+    call('vqa_softmax_ce', ptr(lg), C, ptr(y), ptr(rows), ptr(dl), 16, B, C, 1.0 / B, F32)
+    call('vqa_sum_scale', ptr(rows), ptr(out), B, 1.0 / B)
+    torch.cuda.synchronize()
+    assert abs(float(out) - float(z['loss'])) <= 1e-6 * abs(float(z['loss']))
+    assert rel_err(dl[:, :C], torch.from_numpy(z['dlogits'])) <= 1e-6
+    assert float(dl[:, C:].abs().max()) == 0.0

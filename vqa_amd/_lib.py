@@ -1,0 +1,102 @@
+"""ctypes binding of libvqa_hip.so (the C ABI declared in include/vqa_hip.h).
+
+There is no fallback: if the library is missing or a call fails, an exception
+is raised.  Pointers are raw device addresses taken from torch tensors; the
+stream is torch's current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+F32, BF16 = 0, 1
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libvqa_hip.so')
+
+_p, _i, _l, _f, _u, _z = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_uint, C.c_size_t
+
+# name -> argtypes (stream last); every function returns int unless listed in _RESTYPE
+_SIGNATURES = {
+    'vqa_version': [],
+    'vqa_last_error_string': [],
+    'vqa_process_lengths': [_p, _p, _i, _i, _p],
+    'vqa_embedding_gather': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    'vqa_lstm_cell': [_p, _i, _z, _p, _i, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    'vqa_caption_pool': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    'vqa_inv_norm': [_p, _p, _l, _i, _i, _i, _p],
+    'vqa_attn_lds_bytes': [_i, _i, _i],
+    'vqa_attn_fwd': [_p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    'vqa_attn_bwd': [_p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _i, _p, _i, _p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _p],
+    'vqa_gemm_splitk_hint': [_i, _i, _i],
+    'vqa_gemm_slabs': [_p, _i, _i, _p, _i, _i, _p, _z, _i, _i, _i, _i, _i, _i, _i, _p],
+    'vqa_gemm_fused': [_p, _i, _i, _p, _i, _i, _p, _i, _i, _i, _i, _p, _p, _i, _i, _i, _i, _p],
+    'vqa_epilogue': [_p, _i, _z, _i, _i, _p, _p, _p, _i, _i, _p, _i, _p, _i, _i, _u, _f, _p],
+    'vqa_dropout': [_p, _i, _p, _i, _i, _i, _u, _f, _i, _p],
+    'vqa_fusion_fwd': [_p, _p, _p, _i, _i, _i, _u, _f, _i, _p],
+    'vqa_fusion_bwd': [_p, _i, _z, _i, _p, _p, _p, _p, _i, _i, _i, _u, _f, _i, _p],
+    'vqa_tanh_dropout_bwd': [_p, _i, _z, _p, _i, _p, _i, _i, _i, _u, _f, _i, _p],
+    'vqa_colsum': [_p, _i, _p, _i, _i, _i, _p],
+    'vqa_cast_pad': [_p, _i, _p, _i, _i, _i, _i, _p],
+    'vqa_softmax_ce': [_p, _i, _p, _p, _p, _i, _i, _i, _f, _i, _p],
+    'vqa_sum_scale': [_p, _p, _i, _f, _p],
+    'vqa_argmax_accuracy': [_p, _i, _i, _i, _p, _p, _i, _p, _p, _p],
+    'vqa_adam_step': [_p, _p, _p, _p, _p, _l, _f, _f, _f, _f, _i, _f, _p],
+}
+_RESTYPE = {'vqa_last_error_string': C.c_char_p, 'vqa_attn_lds_bytes': C.c_size_t}
+_NO_STATUS = {'vqa_version', 'vqa_last_error_string', 'vqa_attn_lds_bytes', 'vqa_gemm_splitk_hint'}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+class VqaHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the kernel library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise VqaHipError(f'{LIB_PATH} is missing: build it with `make` (hipcc --offload-arch=gfx950); '
+                              'there is no CPU or PyTorch fallback for the kernels')
+        lib = C.CDLL(LIB_PATH)
+        for name, args in _SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.argtypes = args
+            fn.restype = _RESTYPE.get(name, C.c_int)
+        _lib = lib
+    return _lib
+
+
+def ptr(t):
+    """Device address of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name: str, *args):
+    """Invoke an entry point on the current stream; raise on a non-zero status."""
+    lib = load()
+    fn = getattr(lib, name)
+    if name in _NO_STATUS:
+        return fn(*args)
+    rc = fn(*args, stream())
+    if rc != 0:
+        raise VqaHipError(f'{name} failed ({rc}): {lib.vqa_last_error_string().decode()}')
+    return rc
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    if dt == torch.float32:
+        return F32
+    if dt == torch.bfloat16:
+        return BF16
+    raise VqaHipError(f'unsupported storage dtype {dt}; use torch.float32 or torch.bfloat16')

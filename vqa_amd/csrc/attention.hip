@@ -1,0 +1,348 @@
+// Fused question-conditioned attention over the region grid (gfx950).
+//
+// One workgroup per sample.  Forward, for sample b with R regions:
+//     s_r    = w_a . tanh(P[b,r,:] + qa[b,:]) + c
+//     p      = softmax_r(s)
+//     pooled = sum_r p_r * inv_norm[b,r] * V[b,r,:]          (= sum_r p_r v_hat_r)
+// P (R x A) and V (R x Dv) are each streamed from HBM exactly once with 16-byte
+// per-lane loads; the scores, the probabilities, qa, w_a and the pooled
+// accumulators live in LDS / registers for the whole kernel.
+// Backward streams V once (dp_r = inv_norm_r * d_pooled . V_r), P once
+// (recomputing tanh) and writes dP once.
+#include "common.h"
+#include "vqa_hip.h"
+
+#define ATT_THREADS 1024
+#define ATT_WAVES (ATT_THREADS / 64)
+#define ATT_MAX_R 4096
+
+template <typename T> struct TanhSel { static __device__ __forceinline__ float f(float x) { return fast_tanh(x); } };
+template <> struct TanhSel<float> { static __device__ __forceinline__ float f(float x) { return tanhf(x); } };
+
+// dynamic LDS layout (floats): qa[A] | wa[A] | s[R] | w[R] | red[ATT_THREADS * 8]
+template <typename T>
+__global__ void __launch_bounds__(ATT_THREADS)
+k_attn_fwd(const T* __restrict__ P, int ldP, const T* __restrict__ V, int ldV, const float* __restrict__ qa,
+           int ld_qa, const float* __restrict__ w_a, const float* __restrict__ c_a,
+           const float* __restrict__ inv_norm, float* __restrict__ p_out, T* __restrict__ pooled_t,
+           float* __restrict__ pooled_f32, int ld_pool, int R, int A, int Dv) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* qa_s = smem;
+    float* wa_s = qa_s + A;
+    float* s_s = wa_s + A;
+    float* w_s = s_s + R;
+    float* red = w_s + ((R + 3) & ~3);
+    __shared__ float red2[ATT_WAVES];
+
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const T* Pb = P + (size_t)b * R * ldP;
+    const T* Vb = V + (size_t)b * R * ldV;
+
+    // pooling geometry: thread (grp, cv) owns vector column cv of rows grp, grp + G, ...
+    const int nv = Dv >> 3;
+    const int G = ATT_THREADS / nv > 0 ? ATT_THREADS / nv : 1;
+    const int cpass = (nv + ATT_THREADS - 1) / ATT_THREADS;      // > 1 only when Dv > 8 * ATT_THREADS
+    const int grp = tid / nv, cv = tid % nv;
+    const bool pool_active = (cpass > 1) || (grp < G);
+
+    for (int a = tid; a < A; a += ATT_THREADS) { qa_s[a] = qa[(size_t)b * ld_qa + a]; wa_s[a] = w_a[a]; }
+    __syncthreads();
+
+    // ---- phase 1: scores, one wave per region row --------------------------------
+    const int nva = A >> 3;
+    for (int r = wv; r < R; r += ATT_WAVES) {
+        const T* row = Pb + (size_t)r * ldP;
+        float acc = 0.f;
+        for (int v = lane; v < nva; v += 64) {
+            float x[8];
+            Vec8<T>::load(row + v * 8, x);
+            const f32x4 q0 = *reinterpret_cast<const f32x4*>(qa_s + v * 8);
+            const f32x4 q1 = *reinterpret_cast<const f32x4*>(qa_s + v * 8 + 4);
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(wa_s + v * 8);
+            const f32x4 w1 = *reinterpret_cast<const f32x4*>(wa_s + v * 8 + 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc += w0[i] * TanhSel<T>::f(x[i] + q0[i]);
+                acc += w1[i] * TanhSel<T>::f(x[4 + i] + q1[i]);
+            }
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) s_s[r] = acc + c_a[0];
+    }
+
+    // first pooling loads do not depend on the probabilities: issue them now so
+    // that HBM stays busy across the softmax
+    float pre[2][8];
+    int pre_r[2] = {grp, grp + G};
+    if (cpass == 1 && pool_active) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            if (pre_r[u] < R) Vec8<T>::load(Vb + (size_t)pre_r[u] * ldV + cv * 8, pre[u]);
+    }
+    __syncthreads();
+
+    // ---- phase 2: softmax over regions ---------------------------------------------
+    float mx = -INFINITY;
+    for (int r = tid; r < R; r += ATT_THREADS) mx = fmaxf(mx, s_s[r]);
+    mx = block_max(mx, red2);
+    float se = 0.f;
+    for (int r = tid; r < R; r += ATT_THREADS) se += expf(s_s[r] - mx);
+    se = block_sum(se, red2);
+    const float inv_se = 1.0f / se;
+    for (int r = tid; r < R; r += ATT_THREADS) {
+        const float p = expf(s_s[r] - mx) * inv_se;
+        p_out[(size_t)b * R + r] = p;
+        w_s[r] = p * inv_norm[(size_t)b * R + r];
+    }
+    __syncthreads();
+
+    // ---- phase 3: attention-weighted pooling -----------------------------------------
+    if (cpass == 1) {
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (pool_active) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                if (pre_r[u] < R) {
+                    const float w = w_s[pre_r[u]];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) acc[i] += w * pre[u][i];
+                }
+            int r = grp + 2 * G;
+            for (; r + 3 * G < R; r += 4 * G) {           // 4 independent loads in flight
+                float x0[8], x1[8], x2[8], x3[8];
+                Vec8<T>::load(Vb + (size_t)r * ldV + cv * 8, x0);
+                Vec8<T>::load(Vb + (size_t)(r + G) * ldV + cv * 8, x1);
+                Vec8<T>::load(Vb + (size_t)(r + 2 * G) * ldV + cv * 8, x2);
+                Vec8<T>::load(Vb + (size_t)(r + 3 * G) * ldV + cv * 8, x3);
+                const float w0 = w_s[r], w1 = w_s[r + G], w2 = w_s[r + 2 * G], w3 = w_s[r + 3 * G];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i] += w0 * x0[i] + w1 * x1[i] + w2 * x2[i] + w3 * x3[i];
+            }
+            for (; r < R; r += G) {
+                float x0[8];
+                Vec8<T>::load(Vb + (size_t)r * ldV + cv * 8, x0);
+                const float w0 = w_s[r];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i] += w0 * x0[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) red[(size_t)(grp * nv + cv) * 8 + i] = acc[i];
+        }
+        __syncthreads();
+        // fixed-order sum over the G row groups
+        for (int d = tid; d < Dv; d += ATT_THREADS) {
+            float s = 0.f;
+            for (int g = 0; g < G; ++g) s += red[(size_t)g * Dv + d];
+            if (pooled_f32) pooled_f32[(size_t)b * ld_pool + d] = s;
+            if (pooled_t) pooled_t[(size_t)b * ld_pool + d] = from_f32<T>(s);
+        }
+    } else {
+        // very wide features: each thread walks its vector columns over all rows
+        for (int c = tid; c < nv; c += ATT_THREADS) {
+            float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int r = 0; r < R; ++r) {
+                float x0[8];
+                Vec8<T>::load(Vb + (size_t)r * ldV + c * 8, x0);
+                const float w0 = w_s[r];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i] += w0 * x0[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (pooled_f32) pooled_f32[(size_t)b * ld_pool + c * 8 + i] = acc[i];
+                if (pooled_t) pooled_t[(size_t)b * ld_pool + c * 8 + i] = from_f32<T>(acc[i]);
+            }
+        }
+    }
+}
+
+// Backward.  dynamic LDS (floats): dpool[Dv] | ds[R] | wn[R] (inv_norm) | red[...]
+//   dp_r  = inv_norm_r * (d_pooled . V_r)
+//   ds_r  = p_r * (dp_r - sum_j p_j dp_j)
+//   t     = tanh(P_r + qa);  g = ds_r * w_a * (1 - t^2)
+//   dP_scaled[r, :] = g * inv_norm_r     (so that dW_va = dP_scaled^T V, V un-normalised)
+//   dqa[b, :] = sum_r g ;  dwa_part[b, :] = sum_r ds_r * t ;  dc_part[b] = sum_r ds_r
+template <typename T>
+__global__ void __launch_bounds__(ATT_THREADS)
+k_attn_bwd(const T* __restrict__ P, int ldP, const T* __restrict__ V, int ldV, const float* __restrict__ qa,
+           int ld_qa, const float* __restrict__ w_a, const float* __restrict__ inv_norm,
+           const float* __restrict__ p_in, const float* __restrict__ d_pooled, int ld_dpool,
+           T* __restrict__ dP, int ld_dP, float* __restrict__ dqa_f32, T* __restrict__ dqa_t, int ld_dqa,
+           float* __restrict__ dwa_part, float* __restrict__ dc_part, int R, int A, int Dv) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* dpool_s = smem;
+    float* ds_s = dpool_s + Dv;
+    float* wn_s = ds_s + ((R + 3) & ~3);
+    float* red = wn_s + ((R + 3) & ~3);
+    __shared__ float red2[ATT_WAVES];
+
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const T* Pb = P + (size_t)b * R * ldP;
+    const T* Vb = V + (size_t)b * R * ldV;
+    T* dPb = dP + (size_t)b * R * ld_dP;
+
+    for (int d = tid; d < Dv; d += ATT_THREADS) dpool_s[d] = d_pooled[(size_t)b * ld_dpool + d];
+    for (int r = tid; r < R; r += ATT_THREADS) wn_s[r] = inv_norm[(size_t)b * R + r];
+    __syncthreads();
+
+    // ---- phase A: dp_r, one wave per region row ---------------------------------------
+    const int nv = Dv >> 3;
+    for (int r = wv; r < R; r += ATT_WAVES) {
+        const T* row = Vb + (size_t)r * ldV;
+        float acc = 0.f;
+        for (int v = lane; v < nv; v += 64) {
+            float x[8];
+            Vec8<T>::load(row + v * 8, x);
+            const f32x4 d0 = *reinterpret_cast<const f32x4*>(dpool_s + v * 8);
+            const f32x4 d1 = *reinterpret_cast<const f32x4*>(dpool_s + v * 8 + 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc += d0[i] * x[i] + d1[i] * x[4 + i];
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) ds_s[r] = acc * wn_s[r];          // dp_r for now
+    }
+    __syncthreads();
+
+    // ---- phase B: softmax backward -----------------------------------------------------
+    float dot = 0.f;
+    for (int r = tid; r < R; r += ATT_THREADS) dot += p_in[(size_t)b * R + r] * ds_s[r];
+    dot = block_sum(dot, red2);
+    float dsum = 0.f;
+    for (int r = tid; r < R; r += ATT_THREADS) {
+        const float ds = p_in[(size_t)b * R + r] * (ds_s[r] - dot);
+        ds_s[r] = ds;
+        dsum += ds;
+    }
+    dsum = block_sum(dsum, red2);      // also the barrier that publishes ds_s
+    if (tid == 0 && dc_part) dc_part[b] = dsum;
+
+    // ---- phase C: stream P, write dP, accumulate dqa / dwa --------------------------------
+    const int nva = A >> 3;
+    const int G = ATT_THREADS / nva > 0 ? ATT_THREADS / nva : 1;
+    const int grp = tid / nva, cv = tid % nva;
+    for (int c0 = 0; c0 < nva; c0 += ATT_THREADS) {          // one pass unless A > 8 * ATT_THREADS
+        const int c = c0 + cv;
+        const bool active = (nva > ATT_THREADS) ? (c < nva) : (grp < G);
+        const int rstep = (nva > ATT_THREADS) ? 1 : G;
+        const int rbeg = (nva > ATT_THREADS) ? 0 : grp;
+        float aq[8] = {0, 0, 0, 0, 0, 0, 0, 0}, aw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (active) {
+            float qv[8], wv8[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { qv[i] = qa[(size_t)b * ld_qa + c * 8 + i]; wv8[i] = w_a[c * 8 + i]; }
+            for (int r = rbeg; r < R; r += rstep) {
+                float x[8], o[8];
+                Vec8<T>::load(Pb + (size_t)r * ldP + c * 8, x);
+                const float ds = ds_s[r], wn = wn_s[r];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float t = TanhSel<T>::f(x[i] + qv[i]);
+                    const float g = ds * wv8[i] * (1.0f - t * t);
+                    aq[i] += g;
+                    aw[i] += ds * t;
+                    o[i] = g * wn;
+                }
+                Vec8<T>::store(dPb + (size_t)r * ld_dP + c * 8, o);
+            }
+        }
+        if (nva > ATT_THREADS) {
+            if (active) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    dqa_f32[(size_t)b * ld_dqa + c * 8 + i] = aq[i];
+                    if (dqa_t) dqa_t[(size_t)b * ld_dqa + c * 8 + i] = from_f32<T>(aq[i]);
+                    dwa_part[(size_t)b * ld_dqa + c * 8 + i] = aw[i];
+                }
+            }
+        } else {
+            // fixed-order reduction over the G row groups, dqa then dwa through one buffer
+            __syncthreads();
+            if (active) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) red[(size_t)(grp * nva + cv) * 8 + i] = aq[i];
+            }
+            __syncthreads();
+            for (int a = tid; a < A; a += ATT_THREADS) {
+                float s = 0.f;
+                for (int g = 0; g < G; ++g) s += red[(size_t)g * A + a];
+                dqa_f32[(size_t)b * ld_dqa + a] = s;
+                if (dqa_t) dqa_t[(size_t)b * ld_dqa + a] = from_f32<T>(s);
+            }
+            __syncthreads();
+            if (active) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) red[(size_t)(grp * nva + cv) * 8 + i] = aw[i];
+            }
+            __syncthreads();
+            for (int a = tid; a < A; a += ATT_THREADS) {
+                float s = 0.f;
+                for (int g = 0; g < G; ++g) s += red[(size_t)g * A + a];
+                dwa_part[(size_t)b * ld_dqa + a] = s;
+            }
+        }
+    }
+}
+
+extern "C" {
+
+size_t vqa_attn_lds_bytes(int R, int A, int Dv) {
+    const size_t r4 = (size_t)((R + 3) & ~3);
+    const size_t fwd = (size_t)2 * A + R + r4 + (size_t)ATT_THREADS * 8;
+    const size_t bwd = (size_t)Dv + 2 * r4 + (size_t)ATT_THREADS * 8;
+    return (fwd > bwd ? fwd : bwd) * sizeof(float);
+}
+
+static int attn_check(int B, int R, int A, int Dv, int ldP, int ldV) {
+    VQA_REQUIRE(B >= 0 && R > 0 && A > 0 && Dv > 0, "vqa_attn: sizes must be positive");
+    VQA_REQUIRE(A % 8 == 0 && Dv % 8 == 0 && ldP % 8 == 0 && ldV % 8 == 0 && ldP >= A && ldV >= Dv,
+                "vqa_attn: A, Dv and leading dimensions must be multiples of 8");
+    VQA_REQUIRE(R <= ATT_MAX_R, "vqa_attn: more than 4096 regions per sample");
+    VQA_REQUIRE(vqa_attn_lds_bytes(R, A, Dv) <= 160 * 1024, "vqa_attn: A / Dv / R too large for LDS");
+    return 0;
+}
+
+int vqa_attn_fwd(const void* P, int ldP, const void* V, int ldV, const float* qa, int ld_qa, const float* w_a,
+                 const float* c_a, const float* inv_norm, float* p_out, void* pooled_t, float* pooled_f32,
+                 int ld_pool, int B, int R, int A, int Dv, int dtype, hipStream_t stream) {
+    VQA_REQUIRE(P && V && qa && w_a && c_a && inv_norm && p_out && (pooled_t || pooled_f32), "vqa_attn_fwd: null pointer");
+    if (int rc = attn_check(B, R, A, Dv, ldP, ldV)) return rc;
+    VQA_REQUIRE(ld_qa >= A && ld_pool >= Dv, "vqa_attn_fwd: ld_qa / ld_pool too small");
+    if (B == 0) return 0;
+    const size_t lds = ((size_t)2 * A + R + ((R + 3) & ~3) + (size_t)ATT_THREADS * 8) * sizeof(float);
+    if (dtype == VQA_F32) {
+        VQA_REQUIRE(hipFuncSetAttribute((const void*)k_attn_fwd<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess, "vqa_attn_fwd: cannot reserve LDS");
+        k_attn_fwd<float><<<B, ATT_THREADS, lds, stream>>>((const float*)P, ldP, (const float*)V, ldV, qa, ld_qa, w_a, c_a,
+                                                          inv_norm, p_out, (float*)pooled_t, pooled_f32, ld_pool, R, A, Dv);
+    } else if (dtype == VQA_BF16) {
+        VQA_REQUIRE(hipFuncSetAttribute((const void*)k_attn_fwd<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess, "vqa_attn_fwd: cannot reserve LDS");
+        k_attn_fwd<bf16_t><<<B, ATT_THREADS, lds, stream>>>((const bf16_t*)P, ldP, (const bf16_t*)V, ldV, qa, ld_qa, w_a, c_a,
+                                                           inv_norm, p_out, (bf16_t*)pooled_t, pooled_f32, ld_pool, R, A, Dv);
+    } else return vqa_set_error(-22, "vqa_attn_fwd: dtype");
+    return vqa_check_launch("vqa_attn_fwd");
+}
+
+int vqa_attn_bwd(const void* P, int ldP, const void* V, int ldV, const float* qa, int ld_qa, const float* w_a,
+                 const float* inv_norm, const float* p_in, const float* d_pooled, int ld_dpool, void* dP, int ld_dP,
+                 float* dqa_f32, void* dqa_t, int ld_dqa, float* dwa_part, float* dc_part, int B, int R, int A, int Dv,
+                 int dtype, hipStream_t stream) {
+    VQA_REQUIRE(P && V && qa && w_a && inv_norm && p_in && d_pooled && dP && dqa_f32 && dwa_part, "vqa_attn_bwd: null pointer");
+    if (int rc = attn_check(B, R, A, Dv, ldP, ldV)) return rc;
+    VQA_REQUIRE(ld_qa >= A && ld_dpool >= Dv && ld_dP >= A && ld_dP % 8 == 0 && ld_dqa >= A, "vqa_attn_bwd: leading dimension too small");
+    if (B == 0) return 0;
+    const size_t r4 = (size_t)((R + 3) & ~3);
+    const size_t lds = ((size_t)Dv + 2 * r4 + (size_t)ATT_THREADS * 8) * sizeof(float);
+    if (dtype == VQA_F32) {
+        VQA_REQUIRE(hipFuncSetAttribute((const void*)k_attn_bwd<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess, "vqa_attn_bwd: cannot reserve LDS");
+        k_attn_bwd<float><<<B, ATT_THREADS, lds, stream>>>((const float*)P, ldP, (const float*)V, ldV, qa, ld_qa, w_a, inv_norm,
+                                                          p_in, d_pooled, ld_dpool, (float*)dP, ld_dP, dqa_f32, (float*)dqa_t,
+                                                          ld_dqa, dwa_part, dc_part, R, A, Dv);
+    } else if (dtype == VQA_BF16) {
+        VQA_REQUIRE(hipFuncSetAttribute((const void*)k_attn_bwd<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess, "vqa_attn_bwd: cannot reserve LDS");
+        k_attn_bwd<bf16_t><<<B, ATT_THREADS, lds, stream>>>((const bf16_t*)P, ldP, (const bf16_t*)V, ldV, qa, ld_qa, w_a, inv_norm,
+                                                           p_in, d_pooled, ld_dpool, (bf16_t*)dP, ld_dP, dqa_f32, (bf16_t*)dqa_t,
+                                                           ld_dqa, dwa_part, dc_part, R, A, Dv);
+    } else return vqa_set_error(-22, "vqa_attn_bwd: dtype");
+    return vqa_check_launch("vqa_attn_bwd");
+}
+
+}  // extern "C"

@@ -1,0 +1,550 @@
+// HBM-bound row / elementwise kernels of the VQA step (gfx950).
+//
+// Every kernel streams its operands once with 16-byte (bf16) / 32-byte (fp32)
+// per-lane accesses and computes in fp32.  Storage type T is float or raw bf16.
+#include "common.h"
+#include "vqa_hip.h"
+
+template <typename T> struct Act {
+    static __device__ __forceinline__ float tanh_(float x) { return fast_tanh(x); }
+    static __device__ __forceinline__ float sigm_(float x) { return fast_sigmoid(x); }
+};
+template <> struct Act<float> {   // fp32 storage = the 1e-5 parity mode: libm-accurate
+    static __device__ __forceinline__ float tanh_(float x) { return tanhf(x); }
+    static __device__ __forceinline__ float sigm_(float x) { return 1.0f / (1.0f + expf(-x)); }
+};
+
+// ---------------------------------------------------------------------------
+// question side
+// ---------------------------------------------------------------------------
+__global__ void k_process_lengths(const int64_t* __restrict__ tok, int* __restrict__ len, int B, int L) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    int z = 0;
+    for (int t = 0; t < L; ++t) z += (tok[(size_t)b * L + t] == 0);
+    len[b] = L - z;
+}
+
+// out[row(b,t), 0:width] = table[tok[b,t], 0:width]; width % 8 == 0.
+// time_major: row = t * B + b, else row = b * L + t.  Ids outside the table
+// read the pad row 0.
+template <typename T>
+__global__ void k_embedding_gather(const int64_t* __restrict__ tok, const T* __restrict__ table,
+                                   T* __restrict__ out, int B, int L, int width, int ld_table,
+                                   int ld_out, int n_rows, int time_major) {
+    const int vec_per_row = width >> 3;
+    const long total = (long)B * L * vec_per_row;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int v = (int)(i % vec_per_row);
+        const long bt = i / vec_per_row;
+        const int b = (int)(bt / L), t = (int)(bt % L);
+        int64_t id = tok[bt];
+        if (id < 0 || id >= n_rows) id = 0;
+        const long orow = time_major ? ((long)t * B + b) : bt;
+        float x[8];
+        Vec8<T>::load(table + (size_t)id * ld_table + v * 8, x);
+        Vec8<T>::store(out + (size_t)orow * ld_out + v * 8, x);
+    }
+}
+
+// One LSTM time step after the recurrent GEMM:  gates = sum_s slab[s] + xg_t
+// (xg_t already holds x_t W_ih^T + b_ih + b_hh), order i, f, g, o.
+// Writes c (fp32, in place), h (T, operand of the next step's GEMM) and, for
+// rows whose last valid token is this step, q (fp32 and T).
+template <typename T>
+__global__ void k_lstm_cell(const float* __restrict__ slabs, int nslab, size_t slab_stride,
+                            const T* __restrict__ xg, int ld_xg, float* __restrict__ c,
+                            T* __restrict__ h, int ld_h, const int* __restrict__ len,
+                            float* __restrict__ q32, T* __restrict__ qT, int ld_q,
+                            int B, int H, int t, int L) {
+    const long total = (long)B * H;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / H), j = (int)(i % H);
+        float g[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) g[k] = to_f32<T>(xg[(size_t)b * ld_xg + k * H + j]);
+        for (int s = 0; s < nslab; ++s) {
+            const float* sl = slabs + s * slab_stride + (size_t)b * 4 * H;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) g[k] += sl[k * H + j];
+        }
+        const float ig = Act<T>::sigm_(g[0]), fg = Act<T>::sigm_(g[1]);
+        const float gg = Act<T>::tanh_(g[2]), og = Act<T>::sigm_(g[3]);
+        const float cprev = (t == 0) ? 0.f : c[i];
+        const float cn = fg * cprev + ig * gg;
+        const float hn = og * Act<T>::tanh_(cn);
+        c[i] = cn;
+        h[(size_t)b * ld_h + j] = from_f32<T>(hn);
+        int last = len[b] - 1;
+        if (last < 0) last += L;               // all-pad row: negative index -> last step
+        if (last == t) {
+            q32[(size_t)b * ld_q + j] = hn;
+            qT[(size_t)b * ld_q + j] = from_f32<T>(hn);
+        }
+    }
+}
+
+// caption vector: masked mean of the gathered rows, then L2 normalise; one
+// block per sample; written into columns [col0, col0 + Ec) of out.
+template <typename T>
+__global__ void k_caption_pool(const int64_t* __restrict__ cap, const T* __restrict__ table,
+                               T* __restrict__ out, int Tc, int Ec, int ld_table, int n_rows,
+                               int ld_out, int col0) {
+    __shared__ float red[16];
+    extern __shared__ float acc[];          // Ec floats
+    const int b = blockIdx.x;
+    float cnt = 0.f;
+    for (int t = 0; t < Tc; ++t) cnt += (cap[(size_t)b * Tc + t] != 0) ? 1.f : 0.f;
+    const float inv = 1.0f / fmaxf(cnt, 1e-9f);
+    float ss = 0.f;
+    for (int e = threadIdx.x; e < Ec; e += blockDim.x) {
+        float s = 0.f;
+        for (int t = 0; t < Tc; ++t) {
+            int64_t id = cap[(size_t)b * Tc + t];
+            if (id != 0) {
+                if (id < 0 || id >= n_rows) id = 0;
+                s += to_f32<T>(table[(size_t)id * ld_table + e]);
+            }
+        }
+        s *= inv;
+        acc[e] = s;
+        ss += s * s;
+    }
+    ss = block_sum(ss, red);
+    const float rn = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+    for (int e = threadIdx.x; e < Ec; e += blockDim.x)
+        out[(size_t)b * ld_out + col0 + e] = from_f32<T>(acc[e] * rn);
+}
+
+// ---------------------------------------------------------------------------
+// image side: inv_norm[row] = 1 / max(||V[row,:]||_2, 1e-12); one wave per row
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) k_inv_norm(const T* __restrict__ V, float* __restrict__ inv_norm,
+                                                  long rows, int Dv, int ldV) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const T* p = V + (size_t)row * ldV;
+    float ss = 0.f;
+    for (int v = lane; v < (Dv >> 3); v += 64) {
+        float x[8];
+        Vec8<T>::load(p + v * 8, x);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ss += x[i] * x[i];
+    }
+    ss = wave_sum(ss);
+    if (lane == 0) inv_norm[row] = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+}
+
+// ---------------------------------------------------------------------------
+// generic split-K reduce + epilogue
+//   v = act(row_scale[m] * sum_s slab[s][m][n] + bias[n] + addend[m][n])
+//   out_pre (fp32, optional) = v ; out_post (T or fp32, optional) = v * dropout
+// ---------------------------------------------------------------------------
+template <typename TP>
+__global__ void k_epilogue(const float* __restrict__ slabs, int nslab, size_t slab_stride, int M, int N,
+                           const float* __restrict__ bias, const float* __restrict__ row_scale,
+                           const float* __restrict__ addend, int ld_add, int act, int accurate,
+                           float* __restrict__ out_pre, int ld_pre, TP* __restrict__ out_post, int ld_post,
+                           unsigned seed, unsigned thr, float dscale) {
+    const long total = (long)M * N;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(i / N), n = (int)(i % N);
+        float v = 0.f;
+        for (int s = 0; s < nslab; ++s) v += slabs[s * slab_stride + i];
+        if (row_scale) v *= row_scale[m];
+        if (bias) v += bias[n];
+        if (addend) v += addend[(size_t)m * ld_add + n];
+        if (act == 1) v = accurate ? tanhf(v) : fast_tanh(v);
+        if (out_pre) out_pre[(size_t)m * ld_pre + n] = v;
+        if (out_post) out_post[(size_t)m * ld_post + n] = from_f32<TP>(v * drop_mult(seed, (unsigned)i, thr, dscale));
+    }
+}
+
+// y = x * dropout(idx); x, y of type T, logical shape (M, N)
+template <typename T>
+__global__ void k_dropout(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy, int M, int N,
+                          unsigned seed, unsigned thr, float dscale) {
+    const long total = (long)M * N;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(i / N), n = (int)(i % N);
+        y[(size_t)m * ldy + n] = from_f32<T>(to_f32<T>(x[(size_t)m * ldx + n]) * drop_mult(seed, (unsigned)i, thr, dscale));
+    }
+}
+
+// fusion forward (reference head): x = dropout(tanh(xv * xq))
+template <typename T>
+__global__ void k_fusion_fwd(const float* __restrict__ xv, const float* __restrict__ xq, T* __restrict__ x,
+                             int ldx, int B, int F, unsigned seed, unsigned thr, float dscale) {
+    const long total = (long)B * F;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / F), f = (int)(i % F);
+        const float t = Act<T>::tanh_(xv[i] * xq[i]);
+        x[(size_t)b * ldx + f] = from_f32<T>(t * drop_mult(seed, (unsigned)i, thr, dscale));
+    }
+}
+
+// fusion backward: dx = sum_s slab (first F of ldslab columns) is d loss / d x
+//   dxf  = dx * dropout * (1 - tanh(xv xq)^2)
+//   dzv  = dxf * xq * (1 - xv^2)      (pre-activation grad of linear_v)
+//   dzq  = dxf * xv * (1 - xq^2)      (pre-activation grad of linear_q)
+template <typename T>
+__global__ void k_fusion_bwd(const float* __restrict__ slabs, int nslab, size_t slab_stride, int ldslab,
+                             const float* __restrict__ xv, const float* __restrict__ xq,
+                             T* __restrict__ dzv, T* __restrict__ dzq, int ldz, int B, int F,
+                             unsigned seed, unsigned thr, float dscale) {
+    const long total = (long)B * F;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / F), f = (int)(i % F);
+        float dx = 0.f;
+        for (int s = 0; s < nslab; ++s) dx += slabs[s * slab_stride + (size_t)b * ldslab + f];
+        const float a = xv[i], q = xq[i];
+        const float t = Act<T>::tanh_(a * q);
+        const float dxf = dx * drop_mult(seed, (unsigned)i, thr, dscale) * (1.0f - t * t);
+        dzv[(size_t)b * ldz + f] = from_f32<T>(dxf * q * (1.0f - a * a));
+        dzq[(size_t)b * ldz + f] = from_f32<T>(dxf * a * (1.0f - q * q));
+    }
+}
+
+// backward through y = dropout(tanh(z)):  dz = (sum_s slab) * dropout * (1 - t^2), t = tanh(z) stored fp32
+template <typename T>
+__global__ void k_tanh_drop_bwd(const float* __restrict__ slabs, int nslab, size_t slab_stride,
+                                const float* __restrict__ t_pre, int ld_t, T* __restrict__ dz, int ldz,
+                                int M, int N, unsigned seed, unsigned thr, float dscale) {
+    const long total = (long)M * N;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(i / N), n = (int)(i % N);
+        float d = 0.f;
+        for (int s = 0; s < nslab; ++s) d += slabs[s * slab_stride + i];
+        const float t = t_pre[(size_t)m * ld_t + n];
+        dz[(size_t)m * ldz + n] = from_f32<T>(d * drop_mult(seed, (unsigned)i, thr, dscale) * (1.0f - t * t));
+    }
+}
+
+// out[n] = sum_m X[m, n]   (bias gradients); deterministic order
+template <typename T>
+__global__ void k_colsum(const T* __restrict__ X, int ld, float* __restrict__ out, int M, int N) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int m = 0; m < M; ++m) s += to_f32<T>(X[(size_t)m * ld + n]);
+    out[n] = s;
+}
+
+// cast fp32 -> T with row padding: dst[m, 0:N] = src[m, 0:N], dst[m, N:ld_dst] = 0
+template <typename T>
+__global__ void k_cast_pad(const float* __restrict__ src, int ld_src, T* __restrict__ dst, int ld_dst, int M, int N) {
+    const long total = (long)M * ld_dst;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(i / ld_dst), n = (int)(i % ld_dst);
+        dst[i] = from_f32<T>(n < N ? src[(size_t)m * ld_src + n] : 0.f);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// softmax cross-entropy forward + backward, one block per row
+//   loss_row[b] = logsumexp(z_b) - z_b[y_b];  dz = (softmax(z_b) - onehot(y_b)) * scale
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) k_softmax_ce(const float* __restrict__ logits, int ld,
+                                                    const int64_t* __restrict__ target,
+                                                    float* __restrict__ loss_row, T* __restrict__ dlogits,
+                                                    int ld_d, int C, float scale) {
+    __shared__ float red[8];
+    const int b = blockIdx.x;
+    const float* z = logits + (size_t)b * ld;
+    float mx = -INFINITY;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) mx = fmaxf(mx, z[c]);
+    mx = block_max(mx, red);
+    float se = 0.f;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) se += expf(z[c] - mx);
+    se = block_sum(se, red);
+    const int64_t y = target[b];
+    if (threadIdx.x == 0) loss_row[b] = (y >= 0 && y < C) ? (logf(se) - (z[y] - mx)) : 0.f;
+    if (dlogits) {
+        const float inv = 1.0f / se;
+        for (int c = threadIdx.x; c < ld_d; c += blockDim.x) {
+            float g = 0.f;
+            if (c < C) g = (expf(z[c] - mx) * inv - (c == y ? 1.f : 0.f)) * scale;
+            dlogits[(size_t)b * ld_d + c] = from_f32<T>(g);
+        }
+    }
+}
+
+// out[0] = sum(x[0:n]) * scale, single block, fixed order
+__global__ void __launch_bounds__(256) k_sum_scale(const float* __restrict__ x, float* __restrict__ out, int n, float scale) {
+    __shared__ float red[8];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) s += x[i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) out[0] = s * scale;
+}
+
+// ---------------------------------------------------------------------------
+// argmax (first maximum, NaN counts as maximum, as numpy) + per-type counters
+// one wave per row; counters[0:nt] = count, counters[nt:2nt] = right
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ bool argmax_better(float a, int ia, float b, int ib) {
+    const bool an = a != a, bn = b != b;
+    if (an || bn) return an && (!bn || ia < ib);
+    return a > b || (a == b && ia < ib);
+}
+
+__global__ void __launch_bounds__(256) k_argmax_accuracy(const float* __restrict__ logits, int ld, int B, int C,
+                                                         const int64_t* __restrict__ answer,
+                                                         const int* __restrict__ type_id, int n_types,
+                                                         int64_t* __restrict__ pred,
+                                                         unsigned long long* __restrict__ counters) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const float* z = logits + (size_t)b * ld;
+    float bv = -INFINITY; int bi = 0x7fffffff;
+    for (int c = lane; c < C; c += 64) {
+        const float v = z[c];
+        if (bi == 0x7fffffff || argmax_better(v, c, bv, bi)) { bv = v; bi = c; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (oi != 0x7fffffff && (bi == 0x7fffffff || argmax_better(ov, oi, bv, bi))) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) {
+        pred[b] = bi;
+        if (counters && answer && type_id) {
+            const int t = type_id[b];
+            if (t >= 0 && t < n_types) {
+                atomicAdd(&counters[t], 1ull);
+                if (answer[b] == (int64_t)bi) atomicAdd(&counters[n_types + t], 1ull);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// fused multi-tensor Adam on flat buffers (torch.optim.Adam defaults, no decay)
+//   g <- grad * grad_scale; m, v updated; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
+//   optional shadow[i] = bf16(p[i])
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_adam(float* __restrict__ p, const float* __restrict__ g,
+                                              float* __restrict__ m, float* __restrict__ v,
+                                              bf16_t* __restrict__ shadow, long n, float lr, float b1, float b2,
+                                              float eps, float inv_bc1, float inv_sqrt_bc2, float grad_scale) {
+    const long n4 = n >> 2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        f32x4 pp = reinterpret_cast<f32x4*>(p)[i];
+        const f32x4 gg = reinterpret_cast<const f32x4*>(g)[i];
+        f32x4 mm = reinterpret_cast<f32x4*>(m)[i];
+        f32x4 vv = reinterpret_cast<f32x4*>(v)[i];
+        u16x4 sh;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float gk = gg[k] * grad_scale;
+            mm[k] = b1 * mm[k] + (1.0f - b1) * gk;
+            vv[k] = b2 * vv[k] + (1.0f - b2) * gk * gk;
+            const float denom = sqrtf(vv[k]) * inv_sqrt_bc2 + eps;
+            pp[k] -= lr * inv_bc1 * (mm[k] / denom);
+            sh[k] = f32_to_bf16(pp[k]);
+        }
+        reinterpret_cast<f32x4*>(p)[i] = pp;
+        reinterpret_cast<f32x4*>(m)[i] = mm;
+        reinterpret_cast<f32x4*>(v)[i] = vv;
+        if (shadow) reinterpret_cast<u16x4*>(shadow)[i] = sh;
+    }
+    // tail (n % 4 elements)
+    const long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.x == 0 && i < n) {
+        const float gk = g[i] * grad_scale;
+        const float mk = b1 * m[i] + (1.0f - b1) * gk;
+        const float vk = b2 * v[i] + (1.0f - b2) * gk * gk;
+        const float pk = p[i] - lr * inv_bc1 * (mk / (sqrtf(vk) * inv_sqrt_bc2 + eps));
+        m[i] = mk; v[i] = vk; p[i] = pk;
+        if (shadow) shadow[i] = f32_to_bf16(pk);
+    }
+}
+
+// ===========================================================================
+// C ABI
+// ===========================================================================
+static inline int grid_for(long total, int block, int cap = 2048) {
+    long g = (total + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+#define DISPATCH_T(dtype, CALL)                                      \
+    if ((dtype) == VQA_F32) { using T = float; CALL; }              \
+    else if ((dtype) == VQA_BF16) { using T = bf16_t; CALL; }       \
+    else return vqa_set_error(-22, "dtype must be VQA_F32 or VQA_BF16");
+
+extern "C" {
+
+int vqa_process_lengths(const int64_t* tokens, int32_t* lengths, int B, int L, hipStream_t stream) {
+    VQA_REQUIRE(tokens && lengths && B >= 0 && L > 0, "vqa_process_lengths: bad arguments");
+    if (B == 0) return 0;
+    k_process_lengths<<<(B + 255) / 256, 256, 0, stream>>>(tokens, lengths, B, L);
+    return vqa_check_launch("vqa_process_lengths");
+}
+
+int vqa_embedding_gather(const int64_t* tokens, const void* table, void* out, int B, int L, int width,
+                         int ld_table, int ld_out, int n_rows, int time_major, int dtype, hipStream_t stream) {
+    VQA_REQUIRE(tokens && table && out && B >= 0 && L > 0 && n_rows > 0, "vqa_embedding_gather: bad arguments");
+    VQA_REQUIRE(width > 0 && width % 8 == 0 && ld_table % 8 == 0 && ld_out % 8 == 0 && width <= ld_table && width <= ld_out,
+                "vqa_embedding_gather: width and leading dimensions must be multiples of 8");
+    if (B == 0) return 0;
+    const long total = (long)B * L * (width / 8);
+    DISPATCH_T(dtype, (k_embedding_gather<T><<<grid_for(total, 256), 256, 0, stream>>>(
+        tokens, (const T*)table, (T*)out, B, L, width, ld_table, ld_out, n_rows, time_major)));
+    return vqa_check_launch("vqa_embedding_gather");
+}
+
+int vqa_lstm_cell(const float* slabs, int nslab, size_t slab_stride, const void* xg_t, int ld_xg, float* c,
+                  void* h, int ld_h, const int32_t* lengths, float* q_f32, void* q_t, int ld_q,
+                  int B, int H, int t, int L, int dtype, hipStream_t stream) {
+    VQA_REQUIRE(xg_t && c && h && lengths && q_f32 && q_t && (nslab == 0 || slabs), "vqa_lstm_cell: null pointer");
+    VQA_REQUIRE(B >= 0 && H > 0 && t >= 0 && t < L && ld_xg >= 4 * H && ld_h >= H && ld_q >= H, "vqa_lstm_cell: bad sizes");
+    if (B == 0) return 0;
+    DISPATCH_T(dtype, (k_lstm_cell<T><<<grid_for((long)B * H, 256), 256, 0, stream>>>(
+        slabs, nslab, slab_stride, (const T*)xg_t, ld_xg, c, (T*)h, ld_h, lengths, q_f32, (T*)q_t, ld_q, B, H, t, L)));
+    return vqa_check_launch("vqa_lstm_cell");
+}
+
+int vqa_caption_pool(const int64_t* cap_tokens, const void* table, void* out, int B, int Tc, int Ec,
+                     int ld_table, int n_rows, int ld_out, int col0, int dtype, hipStream_t stream) {
+    VQA_REQUIRE(cap_tokens && table && out && B >= 0 && Tc > 0 && Ec > 0 && n_rows > 0, "vqa_caption_pool: bad arguments");
+    VQA_REQUIRE(col0 >= 0 && col0 + Ec <= ld_out && Ec <= ld_table && Ec <= 12288, "vqa_caption_pool: bad sizes");
+    if (B == 0) return 0;
+    DISPATCH_T(dtype, (k_caption_pool<T><<<B, 128, Ec * sizeof(float), stream>>>(
+        cap_tokens, (const T*)table, (T*)out, Tc, Ec, ld_table, n_rows, ld_out, col0)));
+    return vqa_check_launch("vqa_caption_pool");
+}
+
+int vqa_inv_norm(const void* V, float* inv_norm, long rows, int Dv, int ldV, int dtype, hipStream_t stream) {
+    VQA_REQUIRE(V && inv_norm && rows >= 0 && Dv > 0, "vqa_inv_norm: bad arguments");
+    VQA_REQUIRE(Dv % 8 == 0 && ldV % 8 == 0 && ldV >= Dv, "vqa_inv_norm: Dv and ldV must be multiples of 8");
+    if (rows == 0) return 0;
+    DISPATCH_T(dtype, (k_inv_norm<T><<<(unsigned)((rows + 3) / 4), 256, 0, stream>>>((const T*)V, inv_norm, rows, Dv, ldV)));
+    return vqa_check_launch("vqa_inv_norm");
+}
+
+int vqa_epilogue(const float* slabs, int nslab, size_t slab_stride, int M, int N, const float* bias,
+                 const float* row_scale, const float* addend, int ld_add, int act, float* out_pre, int ld_pre,
+                 void* out_post, int ld_post, int post_dtype, unsigned drop_seed, float drop_p, hipStream_t stream) {
+    VQA_REQUIRE(slabs && nslab >= 1 && M >= 0 && N > 0, "vqa_epilogue: bad arguments");
+    VQA_REQUIRE(out_pre || out_post, "vqa_epilogue: no output");
+    VQA_REQUIRE(act == 0 || act == 1, "vqa_epilogue: act must be 0 (none) or 1 (tanh)");
+    VQA_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "vqa_epilogue: drop_p must be in [0, 1)");
+    if (M == 0) return 0;
+    const unsigned thr = drop_threshold(drop_p);
+    const float ds = 1.0f / (1.0f - drop_p);
+    const int grid = grid_for((long)M * N, 256);
+    if (post_dtype == VQA_F32)
+        k_epilogue<float><<<grid, 256, 0, stream>>>(slabs, nslab, slab_stride, M, N, bias, row_scale, addend, ld_add,
+                                                    act, 1, out_pre, ld_pre, (float*)out_post, ld_post, drop_seed, thr, ds);
+    else if (post_dtype == VQA_BF16)
+        k_epilogue<bf16_t><<<grid, 256, 0, stream>>>(slabs, nslab, slab_stride, M, N, bias, row_scale, addend, ld_add,
+                                                     act, 0, out_pre, ld_pre, (bf16_t*)out_post, ld_post, drop_seed, thr, ds);
+    else return vqa_set_error(-22, "vqa_epilogue: post_dtype");
+    return vqa_check_launch("vqa_epilogue");
+}
+
+int vqa_dropout(const void* x, int ldx, void* y, int ldy, int M, int N, unsigned seed, float p, int dtype,
+                hipStream_t stream) {
+    VQA_REQUIRE(x && y && M >= 0 && N > 0 && p >= 0.f && p < 1.f, "vqa_dropout: bad arguments");
+    if (M == 0) return 0;
+    const unsigned thr = drop_threshold(p);
+    const float ds = 1.0f / (1.0f - p);
+    DISPATCH_T(dtype, (k_dropout<T><<<grid_for((long)M * N, 256), 256, 0, stream>>>((const T*)x, ldx, (T*)y, ldy, M, N, seed, thr, ds)));
+    return vqa_check_launch("vqa_dropout");
+}
+
+int vqa_fusion_fwd(const float* xv, const float* xq, void* x, int ldx, int B, int F, unsigned seed, float p,
+                   int dtype, hipStream_t stream) {
+    VQA_REQUIRE(xv && xq && x && B >= 0 && F > 0 && ldx >= F && p >= 0.f && p < 1.f, "vqa_fusion_fwd: bad arguments");
+    if (B == 0) return 0;
+    const unsigned thr = drop_threshold(p);
+    const float ds = 1.0f / (1.0f - p);
+    DISPATCH_T(dtype, (k_fusion_fwd<T><<<grid_for((long)B * F, 256), 256, 0, stream>>>(xv, xq, (T*)x, ldx, B, F, seed, thr, ds)));
+    return vqa_check_launch("vqa_fusion_fwd");
+}
+
+int vqa_fusion_bwd(const float* slabs, int nslab, size_t slab_stride, int ldslab, const float* xv, const float* xq,
+                   void* dzv, void* dzq, int ldz, int B, int F, unsigned seed, float p, int dtype, hipStream_t stream) {
+    VQA_REQUIRE(slabs && nslab >= 1 && xv && xq && dzv && dzq && B >= 0 && F > 0 && ldz >= F && ldslab >= F,
+                "vqa_fusion_bwd: bad arguments");
+    VQA_REQUIRE(p >= 0.f && p < 1.f, "vqa_fusion_bwd: p must be in [0, 1)");
+    if (B == 0) return 0;
+    const unsigned thr = drop_threshold(p);
+    const float ds = 1.0f / (1.0f - p);
+    DISPATCH_T(dtype, (k_fusion_bwd<T><<<grid_for((long)B * F, 256), 256, 0, stream>>>(
+        slabs, nslab, slab_stride, ldslab, xv, xq, (T*)dzv, (T*)dzq, ldz, B, F, seed, thr, ds)));
+    return vqa_check_launch("vqa_fusion_bwd");
+}
+
+int vqa_tanh_dropout_bwd(const float* slabs, int nslab, size_t slab_stride, const float* t_pre, int ld_t, void* dz,
+                         int ldz, int M, int N, unsigned seed, float p, int dtype, hipStream_t stream) {
+    VQA_REQUIRE(slabs && nslab >= 1 && t_pre && dz && M >= 0 && N > 0 && ldz >= N && ld_t >= N, "vqa_tanh_dropout_bwd: bad arguments");
+    VQA_REQUIRE(p >= 0.f && p < 1.f, "vqa_tanh_dropout_bwd: p must be in [0, 1)");
+    if (M == 0) return 0;
+    const unsigned thr = drop_threshold(p);
+    const float ds = 1.0f / (1.0f - p);
+    DISPATCH_T(dtype, (k_tanh_drop_bwd<T><<<grid_for((long)M * N, 256), 256, 0, stream>>>(
+        slabs, nslab, slab_stride, t_pre, ld_t, (T*)dz, ldz, M, N, seed, thr, ds)));
+    return vqa_check_launch("vqa_tanh_dropout_bwd");
+}
+
+int vqa_colsum(const void* X, int ld, float* out, int M, int N, int dtype, hipStream_t stream) {
+    VQA_REQUIRE(X && out && M >= 0 && N > 0 && ld >= N, "vqa_colsum: bad arguments");
+    DISPATCH_T(dtype, (k_colsum<T><<<(N + 255) / 256, 256, 0, stream>>>((const T*)X, ld, out, M, N)));
+    return vqa_check_launch("vqa_colsum");
+}
+
+int vqa_cast_pad(const float* src, int ld_src, void* dst, int ld_dst, int M, int N, int dtype, hipStream_t stream) {
+    VQA_REQUIRE(src && dst && M >= 0 && N > 0 && ld_src >= N && ld_dst >= N, "vqa_cast_pad: bad arguments");
+    if (M == 0) return 0;
+    DISPATCH_T(dtype, (k_cast_pad<T><<<grid_for((long)M * ld_dst, 256), 256, 0, stream>>>(src, ld_src, (T*)dst, ld_dst, M, N)));
+    return vqa_check_launch("vqa_cast_pad");
+}
+
+int vqa_softmax_ce(const float* logits, int ld, const int64_t* target, float* loss_rows, void* dlogits, int ld_d,
+                   int B, int C, float grad_scale, int dtype, hipStream_t stream) {
+    VQA_REQUIRE(logits && target && loss_rows && B >= 0 && C > 0 && ld >= C, "vqa_softmax_ce: bad arguments");
+    VQA_REQUIRE(!dlogits || ld_d >= C, "vqa_softmax_ce: ld_d < C");
+    if (B == 0) return 0;
+    DISPATCH_T(dtype, (k_softmax_ce<T><<<B, 256, 0, stream>>>(logits, ld, target, loss_rows, (T*)dlogits, ld_d, C, grad_scale)));
+    return vqa_check_launch("vqa_softmax_ce");
+}
+
+int vqa_sum_scale(const float* x, float* out, int n, float scale, hipStream_t stream) {
+    VQA_REQUIRE(x && out && n >= 0, "vqa_sum_scale: bad arguments");
+    k_sum_scale<<<1, 256, 0, stream>>>(x, out, n, scale);
+    return vqa_check_launch("vqa_sum_scale");
+}
+
+int vqa_argmax_accuracy(const float* logits, int ld, int B, int C, const int64_t* answers, const int32_t* type_ids,
+                        int n_types, int64_t* pred, uint64_t* counters, hipStream_t stream) {
+    VQA_REQUIRE(logits && pred && B >= 0 && C > 0 && ld >= C, "vqa_argmax_accuracy: bad arguments");
+    if (B == 0) return 0;
+    k_argmax_accuracy<<<(B + 3) / 4, 256, 0, stream>>>(logits, ld, B, C, answers, type_ids, n_types, pred,
+                                                       (unsigned long long*)counters);
+    return vqa_check_launch("vqa_argmax_accuracy");
+}
+
+int vqa_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* shadow_bf16, long n,
+                  float lr, float beta1, float beta2, float eps, int step, float grad_scale, hipStream_t stream) {
+    VQA_REQUIRE(param && grad && exp_avg && exp_avg_sq && n >= 0 && step >= 1, "vqa_adam_step: bad arguments");
+    VQA_REQUIRE((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0 &&
+                (((uintptr_t)shadow_bf16) & 7) == 0, "vqa_adam_step: buffers must be 16-byte aligned");
+    if (n == 0) return 0;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    k_adam<<<grid_for((n + 3) / 4, 256), 256, 0, stream>>>(param, grad, exp_avg, exp_avg_sq, (bf16_t*)shadow_bf16, n, lr,
+                                                           beta1, beta2, eps, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)),
+                                                           grad_scale);
+    return vqa_check_launch("vqa_adam_step");
+}
+
+}  // extern "C"

@@ -1,0 +1,343 @@
+// GEMMs of the VQA step (gfx950).
+//
+//   C[M,N] = sum_k A(m,k) * B(n,k)
+//
+// Operand storage is described per operand: "k-major" means the contraction
+// index is the contiguous one (A stored [M][K], B stored [N][K] like an
+// nn.Linear weight); otherwise the operand is stored [K][M] / [K][N].  The three
+// products of a linear layer map to
+//     forward   y  = x W^T      A = x  k-major, B = W  k-major
+//     dgrad     dx = dy W       A = dy k-major, B = W  stored [K=N_out][N=K_in]
+//     wgrad     dW = dy^T x     A = dy stored [K=batch][M], B = x stored [K=batch][N]
+//
+// bf16 path: 256-thread workgroups, 4 waves in a 2x2 grid, v_mfma_f32_16x16x32_bf16,
+// BK = 64, register-staged global->LDS double buffer (one barrier per K step).
+// k-major tiles sit in LDS as 128-byte rows with the 16-byte chunk index XORed
+// with (row & 7) (conflict-free ds_read_b128 fragments); [K][M] tiles sit as
+// rows of BM*2+32 bytes and are read with ds_read_b64_tr_b16, which hands each
+// lane the k-contiguous fragment the MFMA wants.
+// fp32 path (the 1e-5 parity mode): a plain LDS-tiled VALU kernel, any strides.
+#include "common.h"
+#include "vqa_hip.h"
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+#define GEMM_BK 64
+
+// ---- epilogues ----------------------------------------------------------------
+struct EpiSlab {          // fp32 partial sums, one slab per K split
+    float* out; size_t slab_stride; int ld;
+    __device__ __forceinline__ void store(int split, int m, int n, float v) const {
+        out[split * slab_stride + (size_t)m * ld + n] = v;
+    }
+};
+struct EpiFused {         // v = act(row_scale[m] * acc + bias[n]); out fp32 or bf16
+    void* out; int ld; const float* bias; const float* row_scale; int act; int out_bf16;
+    __device__ __forceinline__ void store(int, int m, int n, float v) const {
+        if (row_scale) v *= row_scale[m];
+        if (bias) v += bias[n];
+        if (act == 1) v = out_bf16 ? fast_tanh(v) : tanhf(v);
+        if (out_bf16) ((bf16_t*)out)[(size_t)m * ld + n] = f32_to_bf16(v);
+        else ((float*)out)[(size_t)m * ld + n] = v;
+    }
+};
+
+// blocks that share an XCD (blockIdx % 8) get a contiguous range of logical ids
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7, x = bid & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+
+template <int ROWS, bool KMAJOR> struct TileGeom;
+template <int ROWS> struct TileGeom<ROWS, true> {      // [ROWS][64] bf16, 128-B rows, XOR swizzle
+    static constexpr int BYTES = ROWS * 128;
+    static constexpr int CHUNKS = ROWS * 8;
+};
+template <int ROWS> struct TileGeom<ROWS, false> {     // [64][ROWS] bf16, padded rows
+    static constexpr int STRIDE = ROWS * 2 + 32;
+    static constexpr int BYTES = 64 * STRIDE;
+    static constexpr int CHUNKS = ROWS * 8;
+};
+
+// global -> registers for one operand tile (CHUNKS/256 16-byte chunks per thread)
+template <int ROWS, bool KMAJOR>
+__device__ __forceinline__ void tile_load(const bf16_t* __restrict__ X, int ld, int row0, int nrows, int k0, int kend,
+                                          u32x4 (&r)[ROWS / 32]) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < ROWS / 32; ++i) {
+        const int q = tid + 256 * i;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (KMAJOR) {
+            const int row = row0 + (q >> 3), k = k0 + ((q & 7) << 3);
+            if (row < nrows && k < kend) v = *reinterpret_cast<const u32x4*>(X + (size_t)row * ld + k);
+        } else {
+            constexpr int CPR = ROWS / 8;                 // chunks per k-row
+            const int k = k0 + q / CPR, col = row0 + (q % CPR) * 8;
+            if (k < kend && col < nrows) v = *reinterpret_cast<const u32x4*>(X + (size_t)k * ld + col);
+        }
+        r[i] = v;
+    }
+}
+
+template <int ROWS, bool KMAJOR>
+__device__ __forceinline__ void tile_store(char* lds, const u32x4 (&r)[ROWS / 32]) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < ROWS / 32; ++i) {
+        const int q = tid + 256 * i;
+        int off;
+        if (KMAJOR) {
+            const int row = q >> 3, c = q & 7;
+            off = row * 128 + ((c ^ (row & 7)) << 4);
+        } else {
+            constexpr int CPR = ROWS / 8;
+            off = (q / CPR) * TileGeom<ROWS, false>::STRIDE + (q % CPR) * 16;
+        }
+        *reinterpret_cast<u32x4*>(lds + off) = r[i];
+    }
+}
+
+// fragment of the 16 tile rows starting at r0 for K sub-step kk (32 k's)
+template <int ROWS, bool KMAJOR>
+__device__ __forceinline__ bf16x8_t frag_read(const char* lds, int r0, int kk, int lane) {
+    if (KMAJOR) {
+        const int row = r0 + (lane & 15), c = kk * 4 + (lane >> 4);
+        return *reinterpret_cast<const bf16x8_t*>(lds + row * 128 + ((c ^ (row & 7)) << 4));
+    } else {
+        constexpr int S = TileGeom<ROWS, false>::STRIDE;
+        const int g = lane >> 4, li = lane & 15;
+        const int off = (kk * 32 + 8 * g + (li >> 2)) * S + (r0 + 4 * (li & 3)) * 2;
+        typedef s16x4_t __attribute__((address_space(3))) * lds_p;
+        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(lds + off));
+        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(lds + off + 4 * S));
+        s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8_t, v);
+    }
+}
+
+template <int BM, int BN, bool AKM, bool BKM, class Epi>
+__global__ void __launch_bounds__(256)
+k_gemm_bf16(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, int M, int N, int K,
+            int tiles_m, int tiles_n, int k_per_split, Epi epi) {
+    constexpr int A_BYTES = TileGeom<BM, AKM>::BYTES, B_BYTES = TileGeom<BN, BKM>::BYTES;
+    constexpr int STAGE = A_BYTES + B_BYTES;
+    constexpr int MT = BM / 32, NT = BN / 32;            // 16x16 tiles per wave in m / n
+    __shared__ __attribute__((aligned(16))) char lds[2 * STAGE];
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
+    const int L = xcd_remap(blockIdx.x, gridDim.x);
+    const int tiles = tiles_m * tiles_n;
+    const int split = L / tiles, ti = L % tiles;
+    const int m0 = (ti / tiles_n) * BM, n0 = (ti % tiles_n) * BN;
+    const int kbeg = split * k_per_split;
+    const int kend = min(K, kbeg + k_per_split);
+    const int nk = (kend - kbeg + GEMM_BK - 1) / GEMM_BK;
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    u32x4 ra[BM / 32], rb[BN / 32];
+    tile_load<BM, AKM>(A, lda, m0, M, kbeg, kend, ra);
+    tile_load<BN, BKM>(B, ldb, n0, N, kbeg, kend, rb);
+    tile_store<BM, AKM>(lds, ra);
+    tile_store<BN, BKM>(lds + A_BYTES, rb);
+    __syncthreads();
+
+    for (int it = 0; it < nk; ++it) {
+        const char* la = lds + (it & 1) * STAGE;
+        const char* lb = la + A_BYTES;
+        const bool more = it + 1 < nk;
+        if (more) {
+            tile_load<BM, AKM>(A, lda, m0, M, kbeg + (it + 1) * GEMM_BK, kend, ra);
+            tile_load<BN, BKM>(B, ldb, n0, N, kbeg + (it + 1) * GEMM_BK, kend, rb);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8_t fa[MT], fb[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) fa[i] = frag_read<BM, AKM>(la, wm * (BM / 2) + i * 16, kk, lane);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) fb[j] = frag_read<BN, BKM>(lb, wn * (BN / 2) + j * 16, kk, lane);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) {
+            char* nx = lds + ((it + 1) & 1) * STAGE;
+            tile_store<BM, AKM>(nx, ra);
+            tile_store<BN, BKM>(nx + A_BYTES, rb);
+        }
+        __syncthreads();
+    }
+
+    // C fragment: col = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = n0 + wn * (BN / 2) + j * 16 + (lane & 15);
+            const int mb = m0 + wm * (BM / 2) + i * 16 + (lane >> 4) * 4;
+            if (n < N) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (mb + r < M) epi.store(split, mb + r, n, acc[i][j][r]);
+            }
+        }
+}
+
+// ---- fp32 / any-stride VALU kernel -----------------------------------------------
+template <typename T, bool AKM, bool BKM, class Epi>
+__global__ void __launch_bounds__(256)
+k_gemm_valu(const T* __restrict__ A, int lda, const T* __restrict__ B, int ldb, int M, int N, int K,
+            int tiles_m, int tiles_n, int k_per_split, Epi epi) {
+    __shared__ float As[16][68], Bs[16][68];
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int tiles = tiles_m * tiles_n;
+    const int split = blockIdx.x / tiles, ti = blockIdx.x % tiles;
+    const int m0 = (ti / tiles_n) * 64, n0 = (ti % tiles_n) * 64;
+    const int kbeg = split * k_per_split, kend = min(K, kbeg + k_per_split);
+    float acc[4][4] = {};
+    for (int k0 = kbeg; k0 < kend; k0 += 16) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int i, k;
+            if (AKM) { k = tid & 15; i = (tid >> 4) + 16 * r; } else { i = tid & 63; k = (tid >> 6) + 4 * r; }
+            float v = 0.f;
+            if (m0 + i < M && k0 + k < kend)
+                v = to_f32<T>(AKM ? A[(size_t)(m0 + i) * lda + k0 + k] : A[(size_t)(k0 + k) * lda + m0 + i]);
+            As[k][i] = v;
+            if (BKM) { k = tid & 15; i = (tid >> 4) + 16 * r; } else { i = tid & 63; k = (tid >> 6) + 4 * r; }
+            v = 0.f;
+            if (n0 + i < N && k0 + k < kend)
+                v = to_f32<T>(BKM ? B[(size_t)(n0 + i) * ldb + k0 + k] : B[(size_t)(k0 + k) * ldb + n0 + i]);
+            Bs[k][i] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            float a[4], b[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { a[r] = As[k][ty * 4 + r]; b[r] = Bs[k][tx * 4 + r]; }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[r][c] = fmaf(a[r], b[c], acc[r][c]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int m = m0 + ty * 4 + r, n = n0 + tx * 4 + c;
+            if (m < M && n < N) epi.store(split, m, n, acc[r][c]);
+        }
+}
+
+// ---- host side ----------------------------------------------------------------------
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+template <class Epi>
+static int launch_bf16(const void* A, int lda, int akm, const void* B, int ldb, int bkm, int M, int N, int K,
+                       int splitk, const Epi& epi, hipStream_t stream) {
+    int kps = ceil_div(ceil_div(K, splitk), GEMM_BK) * GEMM_BK;
+    const bool big = (long)ceil_div(M, 128) * ceil_div(N, 128) * splitk >= 192;
+    const int bm = big ? 128 : 64;
+    const int tm = ceil_div(M, bm), tn = ceil_div(N, bm);
+    const unsigned grid = (unsigned)(tm * tn * splitk);
+    const bf16_t* a = (const bf16_t*)A; const bf16_t* b = (const bf16_t*)B;
+#define LAUNCH(BMV, AK, BK_)                                                                         \
+    k_gemm_bf16<BMV, BMV, AK, BK_, Epi><<<grid, 256, 0, stream>>>(a, lda, b, ldb, M, N, K, tm, tn, kps, epi)
+    if (big) {
+        if (akm && bkm) LAUNCH(128, true, true);
+        else if (akm && !bkm) LAUNCH(128, true, false);
+        else if (!akm && bkm) LAUNCH(128, false, true);
+        else LAUNCH(128, false, false);
+    } else {
+        if (akm && bkm) LAUNCH(64, true, true);
+        else if (akm && !bkm) LAUNCH(64, true, false);
+        else if (!akm && bkm) LAUNCH(64, false, true);
+        else LAUNCH(64, false, false);
+    }
+#undef LAUNCH
+    return 0;
+}
+
+template <typename T, class Epi>
+static int launch_valu(const void* A, int lda, int akm, const void* B, int ldb, int bkm, int M, int N, int K,
+                       int splitk, const Epi& epi, hipStream_t stream) {
+    const int kps = ceil_div(ceil_div(K, splitk), 16) * 16;
+    const int tm = ceil_div(M, 64), tn = ceil_div(N, 64);
+    const unsigned grid = (unsigned)(tm * tn * splitk);
+    const T* a = (const T*)A; const T* b = (const T*)B;
+    if (akm && bkm) k_gemm_valu<T, true, true, Epi><<<grid, 256, 0, stream>>>(a, lda, b, ldb, M, N, K, tm, tn, kps, epi);
+    else if (akm && !bkm) k_gemm_valu<T, true, false, Epi><<<grid, 256, 0, stream>>>(a, lda, b, ldb, M, N, K, tm, tn, kps, epi);
+    else if (!akm && bkm) k_gemm_valu<T, false, true, Epi><<<grid, 256, 0, stream>>>(a, lda, b, ldb, M, N, K, tm, tn, kps, epi);
+    else k_gemm_valu<T, false, false, Epi><<<grid, 256, 0, stream>>>(a, lda, b, ldb, M, N, K, tm, tn, kps, epi);
+    return 0;
+}
+
+static int gemm_check(const void* A, int lda, int akm, const void* B, int ldb, int bkm, int M, int N, int K,
+                      int dtype, int engine) {
+    VQA_REQUIRE(A && B, "vqa_gemm: null operand");
+    VQA_REQUIRE(M > 0 && N > 0 && K > 0, "vqa_gemm: M, N, K must be positive");
+    VQA_REQUIRE(dtype == VQA_F32 || dtype == VQA_BF16, "vqa_gemm: dtype");
+    VQA_REQUIRE(lda >= (akm ? K : M) && ldb >= (bkm ? K : N), "vqa_gemm: leading dimension smaller than the row");
+    if (dtype == VQA_BF16 && engine == 0) {
+        // the MFMA path moves 16-byte chunks: 8-element granularity on the contiguous index
+        VQA_REQUIRE(lda % 8 == 0 && ldb % 8 == 0, "vqa_gemm: bf16 leading dimensions must be multiples of 8");
+        VQA_REQUIRE((((uintptr_t)A | (uintptr_t)B) & 15) == 0, "vqa_gemm: bf16 operands must be 16-byte aligned");
+        VQA_REQUIRE((!akm && !bkm) || K % 8 == 0, "vqa_gemm: K must be a multiple of 8 for a k-major bf16 operand (zero-pad it)");
+    }
+    return 0;
+}
+
+extern "C" {
+
+// K splits that give roughly one to two workgroups per CU for small-M products
+int vqa_gemm_splitk_hint(int M, int N, int K) {
+    const long t64 = (long)ceil_div(M, 64) * ceil_div(N, 64);
+    if (t64 >= 256) return 1;
+    int s = (int)((384 + t64 - 1) / t64);
+    const int maxs = K / 256 > 0 ? K / 256 : 1;          // keep >= 4 K steps per split
+    if (s > maxs) s = maxs;
+    if (s > 32) s = 32;
+    return s < 1 ? 1 : s;
+}
+
+int vqa_gemm_slabs(const void* A, int lda, int a_kmajor, const void* B, int ldb, int b_kmajor, float* slabs,
+                   size_t slab_stride, int ld_slab, int M, int N, int K, int splitk, int dtype, int engine,
+                   hipStream_t stream) {
+    if (int rc = gemm_check(A, lda, a_kmajor, B, ldb, b_kmajor, M, N, K, dtype, engine)) return rc;
+    VQA_REQUIRE(slabs && splitk >= 1 && splitk <= 64 && ld_slab >= N, "vqa_gemm_slabs: bad slab arguments");
+    VQA_REQUIRE(splitk == 1 || slab_stride >= (size_t)M * ld_slab, "vqa_gemm_slabs: slab_stride too small");
+    EpiSlab epi{slabs, slab_stride, ld_slab};
+    if (dtype == VQA_BF16 && engine == 0) launch_bf16(A, lda, a_kmajor, B, ldb, b_kmajor, M, N, K, splitk, epi, stream);
+    else if (dtype == VQA_BF16) launch_valu<bf16_t>(A, lda, a_kmajor, B, ldb, b_kmajor, M, N, K, splitk, epi, stream);
+    else launch_valu<float>(A, lda, a_kmajor, B, ldb, b_kmajor, M, N, K, splitk, epi, stream);
+    return vqa_check_launch("vqa_gemm_slabs");
+}
+
+int vqa_gemm_fused(const void* A, int lda, int a_kmajor, const void* B, int ldb, int b_kmajor, void* C, int ldc,
+                   int M, int N, int K, const float* bias, const float* row_scale, int act, int out_dtype,
+                   int dtype, int engine, hipStream_t stream) {
+    if (int rc = gemm_check(A, lda, a_kmajor, B, ldb, b_kmajor, M, N, K, dtype, engine)) return rc;
+    VQA_REQUIRE(C && ldc >= N, "vqa_gemm_fused: bad output");
+    VQA_REQUIRE(act == 0 || act == 1, "vqa_gemm_fused: act must be 0 (none) or 1 (tanh)");
+    VQA_REQUIRE(out_dtype == VQA_F32 || out_dtype == VQA_BF16, "vqa_gemm_fused: out_dtype");
+    EpiFused epi{C, ldc, bias, row_scale, act, out_dtype == VQA_BF16};
+    if (dtype == VQA_BF16 && engine == 0) launch_bf16(A, lda, a_kmajor, B, ldb, b_kmajor, M, N, K, 1, epi, stream);
+    else if (dtype == VQA_BF16) launch_valu<bf16_t>(A, lda, a_kmajor, B, ldb, b_kmajor, M, N, K, 1, epi, stream);
+    else launch_valu<float>(A, lda, a_kmajor, B, ldb, b_kmajor, M, N, K, 1, epi, stream);
+    return vqa_check_launch("vqa_gemm_fused");
+}
+
+}  // extern "C"

@@ -1,0 +1,584 @@
+"""VQA attention / fusion / classifier module driven by the HIP kernels.
+
+Keeps the reference module interface (vqa_model/models/model.py:29-79):
+``Cls(vocab_questions, vocab_answers, args, input_size=512)``, attributes
+``args / vocab_questions / vocab_answers / num_classes``, ``forward(input_v,
+input_q[, captions]) -> (B, num_classes)`` un-normalised logits, ``train() /
+eval()`` toggling dropout, ``parameters() / state_dict() / load_state_dict() /
+to()``, with the reference's parameter names (``linear_q``, ``linear_v``,
+``linear_classif1``, ``linear_classif2``, ``seq2vec.embedding``,
+``seq2vec.rnn``).  The reference's image branch (a frozen ResNet-152 followed
+by an unweighted mean over the grid, model.py:156-164) is replaced by
+precomputed region features and question-conditioned attention over them.
+
+All arithmetic runs in libvqa_hip.so; torch only owns the memory, the stream
+and autograd's bookkeeping.  ``forward`` is differentiable through one
+``torch.autograd.Function`` (so ``loss.backward(); optimizer.step()`` of the
+reference's train.py:201-204 work unchanged); ``train_step`` is the fused path
+(forward + softmax-CE + backward + gradient all-reduce + Adam) used for
+throughput.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import call, ptr
+
+# reference constants (model.py:1585-1592)
+VISUAL_OUT = 2048
+QUESTION_OUT = 2400
+FUSION_IN = 1200
+FUSION_HIDDEN = 256
+DROPOUT_V = DROPOUT_Q = DROPOUT_F = 0.5
+
+
+def _pad8(n: int) -> int:
+    return (n + 7) // 8 * 8
+
+
+def site_seed(base_seed: int, step: int, site: int) -> int:
+    """Seed of dropout site `site` (0: visual, 1: question, 2: fused, 3: hidden) at `step`."""
+    x = (base_seed * 0x01000193 + step * 0x9E3779B1 + site * 0x7F4A7C15 + 0x165667B1) & 0xFFFFFFFF
+    x ^= x >> 15
+    x = (x * 0x2C1B3C6D) & 0xFFFFFFFF
+    x ^= x >> 12
+    return x & 0xFFFFFFFF
+
+
+class _Seq2Vec(nn.Module):
+    """Parameter holder with the reference's names (seq2vec.py:27-38): ``embedding``
+    has len(vocab)+1 rows with the pad row 0, ``rnn`` is a single-layer LSTM."""
+
+    def __init__(self, n_vocab: int, emb_size: int, hidden_size: int, gen: torch.Generator):
+        super().__init__()
+        self.embedding = nn.Embedding(n_vocab + 1, emb_size, padding_idx=0)
+        self.rnn = nn.LSTM(input_size=emb_size, hidden_size=hidden_size, num_layers=1)
+        with torch.no_grad():
+            self.embedding.weight.copy_(torch.randn(self.embedding.weight.shape, generator=gen))
+            self.embedding.weight[0].zero_()
+            k = 1.0 / math.sqrt(hidden_size)
+            for p in self.rnn.parameters():
+                p.copy_((torch.rand(p.shape, generator=gen) * 2 - 1) * k)
+
+
+class _Hop(nn.Module):
+    def __init__(self, Dv: int, Hq: int, A: int, with_u: bool):
+        super().__init__()
+        self.linear_va = nn.Linear(Dv, A)
+        self.linear_qa = nn.Linear(Hq, A)
+        self.linear_a = nn.Linear(A, 1)
+        if with_u:
+            self.linear_u = nn.Linear(Dv, Hq)
+
+
+class _VQAFunction(torch.autograd.Function):
+    """The whole module forward as one autograd node; backward hands out the
+    gradients the kernels wrote into the flat gradient buffer."""
+
+    @staticmethod
+    def forward(ctx, model, feats, tokens, captions, *params):
+        logits = model._forward_impl(feats, tokens, captions).clone()
+        ctx.model = model
+        ctx.n_params = len(params)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        model = ctx.model
+        model._backward_from_dense(dlogits)
+        grads = [v.clone() for v in model._grad_views]
+        return (None, None, None, None, *grads)
+
+
+class VQAAttnModel(nn.Module):
+    def __init__(self, vocab_questions: Sequence[str], vocab_answers: Sequence[str], args=None,
+                 input_size: int = 512, *, dtype: torch.dtype = torch.bfloat16, emb_size: int = 620,
+                 question_out: int = QUESTION_OUT, visual_out: int = VISUAL_OUT,
+                 attention_dim: int = FUSION_IN, fusion_in: int = FUSION_IN,
+                 fusion_hidden: int = FUSION_HIDDEN, hops: int = 1, dropout: float = DROPOUT_F,
+                 caption_vocab: int = 0, caption_dim: int = 384, seed: int = 0, gemm_engine: int = 0):
+        super().__init__()
+        self.args = args
+        self.vocab_questions = vocab_questions
+        self.vocab_answers = vocab_answers
+        self.num_classes = len(self.vocab_answers)
+        self.input_size = input_size
+        self.compute_dtype = dtype
+        self.dt = _lib.dtype_code(dtype)
+        self.E, self.Hq, self.Dv = emb_size, question_out, visual_out
+        self.A, self.F, self.Hf = attention_dim, fusion_in, fusion_hidden
+        self.hops, self.drop_p = hops, float(dropout)
+        self.Ec = caption_dim if caption_vocab > 0 else 0
+        self.caption_vocab = caption_vocab
+        self.gemm_engine = gemm_engine
+        for name, v in (('question_out', self.Hq), ('visual_out', self.Dv), ('attention_dim', self.A),
+                        ('fusion_in', self.F), ('fusion_hidden', self.Hf), ('caption_dim', self.Ec)):
+            if v % 8:
+                raise ValueError(f'{name}={v} must be a multiple of 8 (16-byte bf16 chunks)')
+        if hops < 1:
+            raise ValueError('hops must be >= 1')
+
+        gen = torch.Generator().manual_seed(seed)
+        self.seq2vec = _Seq2Vec(len(vocab_questions), emb_size, question_out, gen)
+        for p in self.seq2vec.parameters():          # frozen, as model.py:42-43
+            p.requires_grad = False
+        self.attention = nn.ModuleList([_Hop(self.Dv, self.Hq, self.A, k + 1 < hops) for k in range(hops)])
+        self.linear_q = nn.Linear(self.Hq, self.F)
+        self.linear_v = nn.Linear(self.Dv, self.F)
+        self.linear_classif1 = nn.Linear(self.F + self.Ec, self.Hf)
+        self.linear_classif2 = nn.Linear(self.Hf, self.num_classes)
+        if caption_vocab > 0:
+            self.caption_embedding = nn.Embedding(caption_vocab + 1, caption_dim, padding_idx=0)
+            self.caption_embedding.weight.requires_grad = False
+            with torch.no_grad():
+                self.caption_embedding.weight.copy_(torch.randn(self.caption_embedding.weight.shape, generator=gen))
+                self.caption_embedding.weight[0].zero_()
+        with torch.no_grad():
+            for m in self.modules():
+                if isinstance(m, nn.Linear):
+                    b = 1.0 / math.sqrt(m.in_features)
+                    m.weight.copy_((torch.rand(m.weight.shape, generator=gen) * 2 - 1) * b)
+                    m.bias.copy_((torch.rand(m.bias.shape, generator=gen) * 2 - 1) * b)
+
+        self.base_seed = seed
+        self.step_count = 0           # optimiser steps taken by train_step
+        self.drop_step = 0            # dropout stream position
+        self._flat = None
+        self._ws: Dict[Tuple, Dict[str, torch.Tensor]] = {}
+        self._slab = None
+        self._frozen_key = None
+        self._shadow_fresh = False
+        self._ctx = None
+        self.grad_ready_hook = None   # callable(bucket_index) fired as gradient buckets complete
+
+    # ------------------------------------------------------------------ flat parameter storage
+    def _trainable_order(self) -> List[Tuple[str, nn.Parameter]]:
+        """Trainable parameters in the order backward completes them (classifier
+        first, image projection last); gradient buckets follow this order."""
+        out = [('linear_classif2.weight', self.linear_classif2.weight), ('linear_classif2.bias', self.linear_classif2.bias),
+               ('linear_classif1.weight', self.linear_classif1.weight), ('linear_classif1.bias', self.linear_classif1.bias),
+               ('linear_v.weight', self.linear_v.weight), ('linear_v.bias', self.linear_v.bias),
+               ('linear_q.weight', self.linear_q.weight), ('linear_q.bias', self.linear_q.bias)]
+        for k in reversed(range(self.hops)):
+            hop = self.attention[k]
+            pre = f'attention.{k}.'
+            out += [(pre + 'linear_a.weight', hop.linear_a.weight), (pre + 'linear_a.bias', hop.linear_a.bias),
+                    (pre + 'linear_qa.weight', hop.linear_qa.weight), (pre + 'linear_qa.bias', hop.linear_qa.bias),
+                    (pre + 'linear_va.bias', hop.linear_va.bias)]
+            if k > 0:
+                prev = self.attention[k - 1]
+                ppre = f'attention.{k - 1}.'
+                out += [(ppre + 'linear_u.weight', prev.linear_u.weight), (ppre + 'linear_u.bias', prev.linear_u.bias)]
+            out += [(pre + 'linear_va.weight', hop.linear_va.weight)]
+        return out
+
+    def _materialize(self, device: torch.device):
+        """Move trainable parameters into one flat fp32 buffer (parameters become
+        views of it) with matching flat gradient / bf16 shadow buffers."""
+        order = self._trainable_order()
+        ok = self._flat is not None and self._flat.device == device
+        if ok:
+            for (name, p), (o, n) in zip(order, self._offsets):
+                if p.data_ptr() != self._flat.data_ptr() + 4 * o or p.numel() != n:
+                    ok = False
+                    break
+        if ok:
+            return
+        offsets, total = [], 0
+        for _, p in order:
+            offsets.append((total, p.numel()))
+            total += _pad8(p.numel())
+        flat = torch.zeros(total, dtype=torch.float32, device=device)
+        grad = torch.zeros(total, dtype=torch.float32, device=device)
+        self._grad_views = []
+        self._index = {}
+        for (name, p), (o, n) in zip(order, offsets):
+            flat[o:o + n].copy_(p.detach().reshape(-1).to(device=device, dtype=torch.float32))
+            p.data = flat[o:o + n].view(p.shape)
+            self._grad_views.append(grad[o:o + n].view(p.shape))
+            self._index[name] = (o, n, tuple(p.shape))
+        self._flat, self._flat_grad, self._offsets = flat, grad, offsets
+        self._shadow = torch.zeros(total, dtype=torch.bfloat16, device=device) if self.dt == _lib.BF16 else None
+        self._exp_avg = self._exp_avg_sq = None
+        self._shadow_fresh = False
+        self._shadow_version = -1
+        # bucket boundaries (element ranges of the flat buffer) in completion order
+        names = [n for n, _ in order]
+        cuts = [names.index('linear_v.weight')]
+        for k in reversed(range(self.hops)):
+            cuts += [names.index(f'attention.{k}.linear_a.weight'), names.index(f'attention.{k}.linear_va.weight')]
+        cuts = sorted(set(cuts))
+        starts = [0] + [offsets[c][0] for c in cuts]
+        ends = starts[1:] + [total]
+        self.buckets = [(s, e) for s, e in zip(starts, ends) if e > s]
+        self._bucket_of = {}
+        for (name, _), (o, n) in zip(order, offsets):
+            for bi, (s, e) in enumerate(self.buckets):
+                if s <= o < e:
+                    self._bucket_of[name] = bi
+
+    def _w(self, name: str):
+        """Device pointer + tensor of the compute-dtype copy of a trainable weight."""
+        o, n, shape = self._index[name]
+        src = self._shadow if self.dt == _lib.BF16 else self._flat
+        return src[o:o + n]
+
+    def _f32(self, name: str):
+        o, n, _ = self._index[name]
+        return self._flat[o:o + n]
+
+    def _g(self, name: str):
+        o, n, _ = self._index[name]
+        return self._flat_grad[o:o + n]
+
+    def _refresh_shadow(self):
+        """bf16 copies of the trainable weights.  The fused Adam kernel writes them
+        itself; any torch-side in-place update of a parameter bumps the flat
+        buffer's version counter and triggers a re-cast here."""
+        if self.dt != _lib.BF16:
+            return
+        if self._shadow_fresh and self._shadow_version == self._flat._version:
+            return
+        n = self._flat.numel()
+        call('vqa_cast_pad', ptr(self._flat), n, ptr(self._shadow), n, 1, n, _lib.BF16)
+        self._shadow_fresh = True
+        self._shadow_version = self._flat._version
+
+    def _refresh_frozen(self, device):
+        """Compute-dtype copies of the frozen question / caption encoder weights:
+        embedding table and W_ih zero-padded to a multiple of 8 columns, b_ih + b_hh."""
+        ps = [self.seq2vec.embedding.weight, self.seq2vec.rnn.weight_ih_l0, self.seq2vec.rnn.weight_hh_l0,
+              self.seq2vec.rnn.bias_ih_l0, self.seq2vec.rnn.bias_hh_l0]
+        if self.Ec:
+            ps.append(self.caption_embedding.weight)
+        key = tuple((p.data_ptr(), p._version) for p in ps) + (str(device),)
+        if key == self._frozen_key:
+            return
+        Ep = _pad8(self.E)
+        tdt = self.compute_dtype
+
+        def cast_pad(src, ld_dst):
+            src = src.detach().to(device=device, dtype=torch.float32).contiguous()
+            dst = torch.empty((src.shape[0], ld_dst), dtype=tdt, device=device)
+            call('vqa_cast_pad', ptr(src), src.shape[1], ptr(dst), ld_dst, src.shape[0], src.shape[1], self.dt)
+            return dst
+
+        self._emb_t = cast_pad(ps[0], Ep)
+        self._wih_t = cast_pad(ps[1], Ep)
+        self._whh_t = cast_pad(ps[2], self.Hq)
+        self._lstm_bias = (ps[3].detach().float() + ps[4].detach().float()).to(device).contiguous()
+        if self.Ec:
+            self._cap_t = cast_pad(ps[5], self.Ec)
+        self._frozen_key = key
+
+    # ------------------------------------------------------------------ workspace
+    def _workspace(self, B: int, R: int, L: int, Tc: int, device) -> Dict[str, torch.Tensor]:
+        key = (B, R, L, Tc, str(device))
+        ws = self._ws.get(key)
+        if ws is not None:
+            return ws
+        tdt, f32 = self.compute_dtype, torch.float32
+        Ep, H, A, Dv, F, Hf, Ec = _pad8(self.E), self.Hq, self.A, self.Dv, self.F, self.Hf, self.Ec
+        Cp = _pad8(self.num_classes)
+
+        def z(shape, dt):
+            return torch.zeros(shape, dtype=dt, device=device)
+
+        ws = {
+            'len': z((B,), torch.int32), 'x_emb': z((L * B, Ep), tdt), 'xg': z((L * B, 4 * H), tdt),
+            'c': z((B, H), f32), 'h': z((B, H), tdt), 'q32': z((B, H), f32), 'qT': z((B, H), tdt),
+            'inv_norm': z((B * R,), f32),
+            'pooled_d': z((B, Dv), tdt), 'q_d': z((B, H), tdt),
+            'xv': z((B, F), f32), 'xq': z((B, F), f32), 'x': z((B, F + Ec), tdt),
+            'h1t': z((B, Hf), f32), 'h1d': z((B, Hf), tdt), 'logits': z((B, Cp), f32),
+            'loss_rows': z((B,), f32), 'loss': z((1,), f32), 'dlogits': z((B, Cp), tdt),
+            'dz1': z((B, Hf), tdt), 'dzv': z((B, F), tdt), 'dzq': z((B, F), tdt),
+            'd_pooled': z((B, Dv), f32), 'dP': z((B * R, A), tdt),
+            'dqa32': z((B, A), f32), 'dqaT': z((B, A), tdt), 'dwa_part': z((B, A), f32), 'dc_part': z((B,), f32),
+            'du32': z((B, H), f32), 'duT': z((B, H), tdt),
+            'pred': z((B,), torch.int64),
+        }
+        for k in range(self.hops):
+            ws[f'P{k}'] = z((B * R, A), tdt)
+            ws[f'qa{k}'] = z((B, A), f32)
+            ws[f'p{k}'] = z((B, R), f32)
+            ws[f'pooled{k}'] = z((B, Dv), tdt)
+            if k > 0:
+                ws[f'u32_{k}'] = z((B, H), f32)
+                ws[f'uT_{k}'] = z((B, H), tdt)
+        self._ws[key] = ws
+        return ws
+
+    def _slabs(self, nfloats: int, device) -> torch.Tensor:
+        if self._slab is None or self._slab.numel() < nfloats or self._slab.device != device:
+            self._slab = torch.empty(max(nfloats, 1 << 20), dtype=torch.float32, device=device)
+        return self._slab
+
+    # ------------------------------------------------------------------ kernel helpers
+    def _gemm_slabs(self, A, lda, akm, Bm, ldb, bkm, M, N, K):
+        """fp32 partial sums of A B^T into the slab workspace -> (slab tensor, nslab, stride)."""
+        sk = call('vqa_gemm_splitk_hint', M, N, K)
+        stride = M * N
+        slab = self._slabs(sk * stride, A.device)
+        call('vqa_gemm_slabs', ptr(A), lda, akm, ptr(Bm), ldb, bkm, ptr(slab), stride, N, M, N, K, sk,
+             self.dt, self.gemm_engine)
+        return slab, sk, stride
+
+    def _linear(self, x, ldx, wname, bname, M, N, K, *, act=0, out_pre=None, ld_pre=0, out_post=None, ld_post=0,
+                post_dtype=None, addend=None, ld_add=0, seed=0, p=0.0):
+        """epilogue(x W^T + b) for a small-M product (split-K slabs + fused reduce)."""
+        slab, sk, stride = self._gemm_slabs(x, ldx, 1, self._w(wname), K, 1, M, N, K)
+        call('vqa_epilogue', ptr(slab), sk, stride, M, N, ptr(self._f32(bname)) if bname else None, None,
+             ptr(addend), ld_add, act, ptr(out_pre), ld_pre, ptr(out_post), ld_post,
+             self.dt if post_dtype is None else post_dtype, seed, p)
+
+    def _wgrad(self, dy, ld_dy, x, ldx, wname, M, N, K):
+        """grad(W)[M,N] = dy^T x with dy stored [K][M], x stored [K][N]."""
+        slab, sk, stride = self._gemm_slabs(dy, ld_dy, 0, x, ldx, 0, M, N, K)
+        call('vqa_epilogue', ptr(slab), sk, stride, M, N, None, None, None, 0, 0, ptr(self._g(wname)), N,
+             None, 0, _lib.F32, 0, 0.0)
+
+    def _bucket_done(self, name: str):
+        if self.grad_ready_hook is not None:
+            self.grad_ready_hook(self._bucket_of[name])
+
+    # ------------------------------------------------------------------ forward
+    def _prepare_inputs(self, input_v, input_q, captions):
+        dev = input_q.device if isinstance(input_q, torch.Tensor) and input_q.is_cuda else input_v.device
+        if dev.type != 'cuda':
+            raise _lib.VqaHipError('VQAAttnModel runs on a HIP device only (inputs must be cuda tensors); '
+                                   'there is no CPU path')
+        if input_v.dim() == 4:                       # (B, Dv, H, W) as model.py:159 produces
+            B, Dv, Hh, Ww = input_v.shape
+            input_v = input_v.permute(0, 2, 3, 1).reshape(B, Hh * Ww, Dv)
+        if input_v.dim() != 3 or input_v.shape[2] != self.Dv:
+            raise ValueError(f'image_feats must be (B, R, {self.Dv}) or (B, {self.Dv}, H, W)')
+        feats = input_v.to(self.compute_dtype).contiguous()
+        tokens = input_q.long().contiguous()
+        if tokens.dim() != 2 or tokens.shape[0] != feats.shape[0]:
+            raise ValueError('question_tokens must be (B, L) with the batch of image_feats')
+        if self.Ec:
+            if captions is None:
+                raise ValueError('this model was built with a caption stream: pass captions (B, Tc) int64')
+            captions = captions.long().contiguous()
+        else:
+            captions = None
+        return feats, tokens, captions
+
+    def forward(self, input_v, input_q, captions=None):
+        feats, tokens, captions = self._prepare_inputs(input_v, input_q, captions)
+        self._materialize(feats.device)
+        params = [p for _, p in self._trainable_order()]
+        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+            return _VQAFunction.apply(self, feats, tokens, captions, *params)
+        # the returned tensor is a copy: the workspace is reused by the next call
+        return self._forward_impl(feats, tokens, captions).clone()
+
+    def _drop_seeds(self):
+        if not self.training or self.drop_p <= 0.0:
+            return (0, 0, 0, 0), 0.0
+        self.drop_step += 1
+        return tuple(site_seed(self.base_seed, self.drop_step, s) for s in range(4)), self.drop_p
+
+    def encode_question(self, tokens: torch.Tensor, ws=None) -> torch.Tensor:
+        """Embedding gather + LSTM + last-valid-step selection -> q (B, Hq) fp32."""
+        B, L = tokens.shape
+        dev = tokens.device
+        self._refresh_frozen(dev)
+        if ws is None:
+            ws = self._workspace(B, 1, L, 0, dev)
+        Ep, H, dt = _pad8(self.E), self.Hq, self.dt
+        call('vqa_process_lengths', ptr(tokens), ptr(ws['len']), B, L)
+        call('vqa_embedding_gather', ptr(tokens), ptr(self._emb_t), ptr(ws['x_emb']), B, L, Ep, Ep, Ep,
+             self._emb_t.shape[0], 1, dt)
+        call('vqa_gemm_fused', ptr(ws['x_emb']), Ep, 1, ptr(self._wih_t), Ep, 1, ptr(ws['xg']), 4 * H,
+             L * B, 4 * H, Ep, ptr(self._lstm_bias), None, 0, dt, dt, self.gemm_engine)
+        esz = ws['xg'].element_size()
+        for t in range(L):
+            xg_t = ws['xg'].data_ptr() + t * B * 4 * H * esz
+            if t == 0:
+                slab, sk, stride = None, 0, 0
+            else:
+                slab, sk, stride = self._gemm_slabs(ws['h'], H, 1, self._whh_t, H, 1, B, 4 * H, H)
+            call('vqa_lstm_cell', ptr(slab), sk, stride, xg_t, 4 * H, ptr(ws['c']), ptr(ws['h']), H, ptr(ws['len']),
+                 ptr(ws['q32']), ptr(ws['qT']), H, B, H, t, L, dt)
+        return ws['q32']
+
+    def _forward_impl(self, feats, tokens, captions):
+        B, R, Dv = feats.shape
+        L = tokens.shape[1]
+        dev = feats.device
+        Tc = captions.shape[1] if captions is not None else 0
+        self._materialize(dev)
+        self._refresh_shadow()
+        ws = self._workspace(B, R, L, Tc, dev)
+        H, A, F, Hf, Ec, C, Cp, dt = self.Hq, self.A, self.F, self.Hf, self.Ec, self.num_classes, _pad8(self.num_classes), self.dt
+        seeds, p = self._drop_seeds()
+
+        self.encode_question(tokens, ws)
+        call('vqa_inv_norm', ptr(feats), ptr(ws['inv_norm']), B * R, Dv, Dv, dt)
+        u32, uT = ws['q32'], ws['qT']
+        for k in range(self.hops):
+            pre = f'attention.{k}.'
+            call('vqa_gemm_fused', ptr(feats), Dv, 1, ptr(self._w(pre + 'linear_va.weight')), Dv, 1, ptr(ws[f'P{k}']), A,
+                 B * R, A, Dv, ptr(self._f32(pre + 'linear_va.bias')), ptr(ws['inv_norm']), 0, dt, dt, self.gemm_engine)
+            self._linear(uT, H, pre + 'linear_qa.weight', pre + 'linear_qa.bias', B, A, H, out_pre=ws[f'qa{k}'], ld_pre=A)
+            call('vqa_attn_fwd', ptr(ws[f'P{k}']), A, ptr(feats), Dv, ptr(ws[f'qa{k}']), A,
+                 ptr(self._f32(pre + 'linear_a.weight')), ptr(self._f32(pre + 'linear_a.bias')), ptr(ws['inv_norm']),
+                 ptr(ws[f'p{k}']), ptr(ws[f'pooled{k}']), None, Dv, B, R, A, Dv, dt)
+            if k + 1 < self.hops:
+                self._linear(ws[f'pooled{k}'], Dv, pre + 'linear_u.weight', pre + 'linear_u.bias', B, H, Dv,
+                             addend=u32, ld_add=H, out_pre=ws[f'u32_{k + 1}'], ld_pre=H, out_post=ws[f'uT_{k + 1}'], ld_post=H)
+                u32, uT = ws[f'u32_{k + 1}'], ws[f'uT_{k + 1}']
+        pooled = ws[f'pooled{self.hops - 1}']
+        call('vqa_dropout', ptr(pooled), Dv, ptr(ws['pooled_d']), Dv, B, Dv, seeds[0], p, dt)
+        call('vqa_dropout', ptr(ws['qT']), H, ptr(ws['q_d']), H, B, H, seeds[1], p, dt)
+        self._linear(ws['pooled_d'], Dv, 'linear_v.weight', 'linear_v.bias', B, F, Dv, act=1, out_pre=ws['xv'], ld_pre=F)
+        self._linear(ws['q_d'], H, 'linear_q.weight', 'linear_q.bias', B, F, H, act=1, out_pre=ws['xq'], ld_pre=F)
+        call('vqa_fusion_fwd', ptr(ws['xv']), ptr(ws['xq']), ptr(ws['x']), F + Ec, B, F, seeds[2], p, dt)
+        if Ec:
+            call('vqa_caption_pool', ptr(captions), ptr(self._cap_t), ptr(ws['x']), B, Tc, Ec, Ec,
+                 self._cap_t.shape[0], F + Ec, F, dt)
+        self._linear(ws['x'], F + Ec, 'linear_classif1.weight', 'linear_classif1.bias', B, Hf, F + Ec, act=1,
+                     out_pre=ws['h1t'], ld_pre=Hf, out_post=ws['h1d'], ld_post=Hf, seed=seeds[3], p=p)
+        self._linear(ws['h1d'], Hf, 'linear_classif2.weight', 'linear_classif2.bias', B, C, Hf,
+                     out_pre=ws['logits'], ld_pre=Cp)
+        self._ctx = (ws, feats, B, R, L, seeds, p)
+        return ws['logits'][:, :C]
+
+    # ------------------------------------------------------------------ backward
+    def _backward_from_dense(self, dlogits: torch.Tensor):
+        """Backward from an arbitrary d loss / d logits (B, C) tensor (autograd path)."""
+        ws, feats, B, R, L, seeds, p = self._ctx
+        C, Cp = self.num_classes, _pad8(self.num_classes)
+        d = dlogits.to(torch.float32).contiguous()
+        call('vqa_cast_pad', ptr(d), C, ptr(ws['dlogits']), Cp, B, C, self.dt)
+        self._backward_impl()
+
+    def _backward_impl(self):
+        """Gradients of every trainable parameter from ws['dlogits'] into the flat gradient buffer."""
+        ws, feats, B, R, L, seeds, p = self._ctx
+        H, A, Dv, F, Hf, Ec, C, Cp, dt = self.Hq, self.A, self.Dv, self.F, self.Hf, self.Ec, self.num_classes, _pad8(self.num_classes), self.dt
+        g = self._g
+        # classifier
+        self._wgrad(ws['dlogits'], Cp, ws['h1d'], Hf, 'linear_classif2.weight', C, Hf, B)
+        call('vqa_colsum', ptr(ws['dlogits']), Cp, ptr(g('linear_classif2.bias')), B, C, dt)
+        slab, sk, st = self._gemm_slabs(ws['dlogits'], Cp, 1, self._w('linear_classif2.weight'), Hf, 0, B, Hf, C)
+        call('vqa_tanh_dropout_bwd', ptr(slab), sk, st, ptr(ws['h1t']), Hf, ptr(ws['dz1']), Hf, B, Hf, seeds[3], p, dt)
+        self._wgrad(ws['dz1'], Hf, ws['x'], F + Ec, 'linear_classif1.weight', Hf, F + Ec, B)
+        call('vqa_colsum', ptr(ws['dz1']), Hf, ptr(g('linear_classif1.bias')), B, Hf, dt)
+        self._bucket_done('linear_classif1.bias')
+        # fusion
+        slab, sk, st = self._gemm_slabs(ws['dz1'], Hf, 1, self._w('linear_classif1.weight'), F + Ec, 0, B, F + Ec, Hf)
+        call('vqa_fusion_bwd', ptr(slab), sk, st, F + Ec, ptr(ws['xv']), ptr(ws['xq']), ptr(ws['dzv']), ptr(ws['dzq']),
+             F, B, F, seeds[2], p, dt)
+        self._wgrad(ws['dzv'], F, ws['pooled_d'], Dv, 'linear_v.weight', F, Dv, B)
+        call('vqa_colsum', ptr(ws['dzv']), F, ptr(g('linear_v.bias')), B, F, dt)
+        self._wgrad(ws['dzq'], F, ws['q_d'], H, 'linear_q.weight', F, H, B)
+        call('vqa_colsum', ptr(ws['dzq']), F, ptr(g('linear_q.bias')), B, F, dt)
+        self._bucket_done('linear_q.bias')
+        slab, sk, st = self._gemm_slabs(ws['dzv'], F, 1, self._w('linear_v.weight'), Dv, 0, B, Dv, F)
+        call('vqa_epilogue', ptr(slab), sk, st, B, Dv, None, None, None, 0, 0, None, 0, ptr(ws['d_pooled']), Dv,
+             _lib.F32, seeds[0], p)
+        # attention hops, last to first
+        du_carry = None
+        for k in reversed(range(self.hops)):
+            pre = f'attention.{k}.'
+            uT = ws['qT'] if k == 0 else ws[f'uT_{k}']
+            call('vqa_attn_bwd', ptr(ws[f'P{k}']), A, ptr(feats), Dv, ptr(ws[f'qa{k}']), A,
+                 ptr(self._f32(pre + 'linear_a.weight')), ptr(ws['inv_norm']), ptr(ws[f'p{k}']), ptr(ws['d_pooled']), Dv,
+                 ptr(ws['dP']), A, ptr(ws['dqa32']), ptr(ws['dqaT']), A, ptr(ws['dwa_part']), ptr(ws['dc_part']),
+                 B, R, A, Dv, dt)
+            call('vqa_colsum', ptr(ws['dwa_part']), A, ptr(g(pre + 'linear_a.weight')), B, A, _lib.F32)
+            call('vqa_sum_scale', ptr(ws['dc_part']), ptr(g(pre + 'linear_a.bias')), B, 1.0)
+            call('vqa_colsum', ptr(ws['dqa32']), A, ptr(g(pre + 'linear_qa.bias')), B, A, _lib.F32)
+            call('vqa_colsum', ptr(ws['dqa32']), A, ptr(g(pre + 'linear_va.bias')), B, A, _lib.F32)
+            self._wgrad(ws['dqaT'], A, uT, H, pre + 'linear_qa.weight', A, H, B)
+            if k > 0:
+                ppre = f'attention.{k - 1}.'
+                slab, sk, st = self._gemm_slabs(ws['dqaT'], A, 1, self._w(pre + 'linear_qa.weight'), H, 0, B, H, A)
+                call('vqa_epilogue', ptr(slab), sk, st, B, H, None, None, ptr(du_carry), H, 0, ptr(ws['du32']), H,
+                     ptr(ws['duT']), H, dt, 0, 0.0)
+                du_carry = ws['du32']
+                self._wgrad(ws['duT'], H, ws[f'pooled{k - 1}'], Dv, ppre + 'linear_u.weight', H, Dv, B)
+                call('vqa_colsum', ptr(ws['du32']), H, ptr(g(ppre + 'linear_u.bias')), B, H, _lib.F32)
+            self._bucket_done(pre + 'linear_va.bias')
+            self._wgrad(ws['dP'], A, feats, Dv, pre + 'linear_va.weight', A, Dv, B * R)
+            self._bucket_done(pre + 'linear_va.weight')
+            if k > 0:
+                slab, sk, st = self._gemm_slabs(ws['duT'], H, 1, self._w(ppre + 'linear_u.weight'), Dv, 0, B, Dv, H)
+                call('vqa_epilogue', ptr(slab), sk, st, B, Dv, None, None, None, 0, 0, ptr(ws['d_pooled']), Dv,
+                     None, 0, _lib.F32, 0, 0.0)
+
+    # ------------------------------------------------------------------ loss / prediction / step
+    def loss_and_grad_logits(self, answers: torch.Tensor) -> torch.Tensor:
+        """Fused softmax cross-entropy (mean) of the last forward + its gradient into the
+        backward workspace.  Returns the 1-element device tensor holding the loss."""
+        ws, feats, B, R, L, seeds, p = self._ctx
+        C, Cp = self.num_classes, _pad8(self.num_classes)
+        ans = answers.long().contiguous()
+        call('vqa_softmax_ce', ptr(ws['logits']), Cp, ptr(ans), ptr(ws['loss_rows']), ptr(ws['dlogits']), Cp, B, C,
+             1.0 / B, self.dt)
+        call('vqa_sum_scale', ptr(ws['loss_rows']), ptr(ws['loss']), B, 1.0 / B)
+        return ws['loss']
+
+    def predict(self, logits: Optional[torch.Tensor] = None, answers=None, type_ids=None, counters=None, n_types: int = 4):
+        """First-max argmax of the last forward's logits (train.py:106); optionally
+        accumulates per-question-type count / right counters on the device."""
+        ws, feats, B, R, L, seeds, p = self._ctx
+        C, Cp = self.num_classes, _pad8(self.num_classes)
+        call('vqa_argmax_accuracy', ptr(ws['logits']), Cp, B, C, ptr(answers), ptr(type_ids), n_types, ptr(ws['pred']),
+             ptr(counters))
+        return ws['pred']
+
+    def adam_step(self, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, grad_scale: float = 1.0):
+        """One fused Adam update of every trainable parameter from the flat gradient buffer."""
+        if self._exp_avg is None:
+            self._exp_avg = torch.zeros_like(self._flat)
+            self._exp_avg_sq = torch.zeros_like(self._flat)
+        self.step_count += 1
+        call('vqa_adam_step', ptr(self._flat), ptr(self._flat_grad), ptr(self._exp_avg), ptr(self._exp_avg_sq),
+             ptr(self._shadow), self._flat.numel(), lr, betas[0], betas[1], eps, self.step_count, grad_scale)
+        self._shadow_fresh = self.dt == _lib.BF16
+        self._shadow_version = self._flat._version
+
+    def train_step(self, input_v, input_q, answers, captions=None, lr: float = 1e-5, reducer=None) -> torch.Tensor:
+        """forward + loss + backward (+ gradient all-reduce through `reducer`) + Adam
+        (train.py:200-204 in one call).  Returns the loss as a 1-element device tensor."""
+        feats, tokens, captions = self._prepare_inputs(input_v, input_q, captions)
+        self._materialize(feats.device)
+        with torch.no_grad():
+            self._forward_impl(feats, tokens, captions)
+            loss = self.loss_and_grad_logits(answers)
+            if reducer is not None:
+                reducer.begin(self)
+                self.grad_ready_hook = reducer.bucket_ready
+            try:
+                self._backward_impl()
+            finally:
+                self.grad_ready_hook = None
+            scale = 1.0
+            if reducer is not None:
+                scale = reducer.finish()
+            self.adam_step(lr, grad_scale=scale)
+        return loss
+
+    # ------------------------------------------------------------------ torch plumbing
+    def _apply(self, fn, *a, **kw):
+        out = super()._apply(fn, *a, **kw)
+        self._flat = None               # parameters moved: rebuild the flat views lazily
+        self._frozen_key = None
+        self._ws.clear()
+        self._slab = None
+        return out
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        out = super().load_state_dict(state_dict, strict=strict, **kw)
+        self._shadow_fresh = False
+        self._frozen_key = None
+        return out
