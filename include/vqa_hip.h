@@ -15,7 +15,9 @@
  *     weights; arithmetic is fp32 (bf16 MFMA products accumulate in fp32);
  *   - matrices are row-major with an explicit leading dimension (elements).
  *     Feature dimensions and leading dimensions of `dtype` matrices are
- *     multiples of 8 elements (16-byte chunks); callers zero-pad.
+ *     multiples of 8 elements (16-byte chunks); callers zero-pad.  A GEMM
+ *     operand stored with k contiguous whose K is not a multiple of 8 must be
+ *     zero-filled up to the next multiple of 8 within its leading dimension.
  *   - dropout is a counter-based hash of (seed, logical element index):
  *     keep iff murmur3_fmix32(index * 0x9E3779B1 + seed) >= p * 2^32, kept
  *     values scaled by 1/(1-p); p == 0 disables it.

@@ -295,7 +295,8 @@ static int gemm_check(const void* A, int lda, int akm, const void* B, int ldb, i
         // the MFMA path moves 16-byte chunks: 8-element granularity on the contiguous index
         VQA_REQUIRE(lda % 8 == 0 && ldb % 8 == 0, "vqa_gemm: bf16 leading dimensions must be multiples of 8");
         VQA_REQUIRE((((uintptr_t)A | (uintptr_t)B) & 15) == 0, "vqa_gemm: bf16 operands must be 16-byte aligned");
-        VQA_REQUIRE((!akm && !bkm) || K % 8 == 0, "vqa_gemm: K must be a multiple of 8 for a k-major bf16 operand (zero-pad it)");
+        // a k-major operand whose K is not a multiple of 8 must be zero-padded by the caller up to
+        // the next multiple of 8 inside its leading dimension (the last chunk is read whole)
     }
     return 0;
 }
