@@ -1,0 +1,159 @@
+"""Throughput of the VQA train step on N MI355X of one node.
+
+    python bench.py --gpus 1 --steps 30 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = forward + softmax-CE + backward + gradient all-reduce + Adam on one
+synthetic VQA-v2-shaped batch per rank (256 samples, 14x14x2048 bf16 region
+features, 14-token questions, 3000 answers; device-resident, several distinct
+batches in rotation so that the 256 MiB Infinity Cache cannot hold the inputs).
+Dropout is on (training mode).  Rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+METRIC = 'train samples/sec (whole node) at 1/2/4/8 MI355X; fused-attn HBM GB/s % peak'
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak
+
+
+def synth_batches(n, B, R, Dv, L, Vq, C, device, seed, dtype):
+    g = torch.Generator(device=device).manual_seed(seed)
+    out = []
+    for _ in range(n):
+        feats = torch.randn((B, R, Dv), device=device, generator=g).clamp_min_(0).to(dtype)
+        lens = torch.randint(3, L + 1, (B,), device=device, generator=g)
+        tok = torch.randint(1, Vq + 1, (B, L), device=device, generator=g)
+        pos = torch.arange(L, device=device)[None, :]
+        tok = torch.where(pos < (lens[:, None] - 1), tok, torch.zeros_like(tok))
+        ans = torch.randint(0, C, (B,), device=device, generator=g)
+        out.append((feats, tok, ans))
+    return out
+
+
+def cpu_baseline(B, R, Dv, L, Vq, C, threads):
+    """The CPU oracle (a port of the reference's arithmetic, fp32) timed on the host cores
+    on a bounded sample: a few steps of fwd + loss + bwd + Adam at the per-GPU batch."""
+    from oracle import vqa_ref
+    torch.set_num_threads(threads)
+    Bs = B
+    p = vqa_ref.init_params(vq=Vq, C=C, E=620, Hq=2400, Dv=Dv, A=1200, F=1200, Hf=256, seed=0)
+    names = vqa_ref.trainable_names(p)
+    m = {k: torch.zeros_like(p[k]) for k in names}
+    v = {k: torch.zeros_like(p[k]) for k in names}
+    b = vqa_ref.synthetic_batch(Bs, R, Dv, L, Vq, C, seed=42)
+    seeds = [vqa_ref.site_seed(0, 1, s) for s in range(4)]
+
+    def step(i):
+        _, _, g = vqa_ref.loss_and_grads(p, b['feats'], b['tokens'], b['answers'], None, 1, drop_seeds=seeds)
+        for k in names:
+            vqa_ref.adam_step(p[k], g[k], m[k], v[k], i, 1e-5)
+
+    step(1)                                   # warm-up (allocator, thread pool)
+    t0 = time.perf_counter()
+    n = 6
+    for i in range(n):
+        step(2 + i)
+    dt = (time.perf_counter() - t0) / n
+    return {'value': Bs / dt, 'unit': 'samples/s', 'cores': threads, 'kind': 'port',
+            'sample': f'{n} timed steps (fwd+CE+bwd+Adam, fp32, dropout on) of the CPU oracle at the per-GPU '
+                      f'batch {Bs}, same model widths and input shapes, after 1 warm-up step'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=256, help='per-GPU batch')
+    ap.add_argument('--regions', type=int, default=196)
+    ap.add_argument('--hops', type=int, default=1)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=dev)
+
+    from vqa_amd.model import VQAAttnModel
+    from vqa_amd.parallel import GradReducer
+
+    B, R, Dv, L, Vq, C = args.batch, args.regions, 2048, 14, 10000, 3000
+    model = VQAAttnModel(['w'] * Vq, ['a'] * C, None, dtype=torch.bfloat16, hops=args.hops, seed=0).to(dev)
+    model.train()
+    reducer = GradReducer() if world > 1 else None
+    nb = max(2, min(4, (320 << 20) // (B * R * Dv * 2) + 1))      # > 256 MiB of features in rotation
+    batches = synth_batches(nb, B, R, Dv, L, Vq, C, dev, 42 + rank, torch.bfloat16)
+
+    def step(i):
+        f, t, a = batches[i % nb]
+        return model.train_step(f, t, a, lr=1e-5, reducer=reducer)
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    model.kernel_events = {}
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+
+    if rank == 0:
+        ev = model.kernel_events.get('attn_fwd', [])
+        k6_ms = sum(s.elapsed_time(e) for s, e in ev) / max(len(ev), 1)
+        # algorithmic bytes of the fused attention forward per sample and hop (bf16):
+        # P (R*A) + V (R*Dv) + qa (A) + pooled (Dv) at 2 B, inv_norm (R) + p (R) at 4 B
+        A = model.A
+        k6_bytes = B * (2 * R * A + 2 * R * Dv + 2 * A + 4 * R + 4 * R + 2 * Dv)
+        achieved = k6_bytes / (k6_ms * 1e-3) / 1e9 if k6_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, 'profiles', 'attn_fwd_traffic.json')
+        if os.path.exists(tpath) and B == 256 and R == 196 and args.hops == 1:
+            traffic = json.load(open(tpath)).get('hbm_bytes_per_launch')
+        out = {
+            'metric': METRIC, 'value': world * B * args.steps / elapsed, 'unit': 'samples/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+            'config': {'workload': f'VQA-v2-shaped synthetic, {R} regions x {Dv} bf16 precomputed feats, '
+                                   f'{L}-token questions, {C} answers, batch {B}/GPU, {args.hops} attention hop(s), '
+                                   f'fwd+CE+bwd+all-reduce+Adam, dropout on',
+                       'global_batch': world * B, 'parallelism': f'dp{world}'},
+            'roofline': {'bound': 'hbm', 'kernel': 'k_attn_fwd (fused attention forward)', 'achieved': achieved,
+                         'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                         'avg_launch_ms': k6_ms, 'algorithmic_bytes_per_launch': k6_bytes},
+            'loss': float(loss),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(B, R, Dv, L, Vq, C, threads=min(16, os.cpu_count() or 1))
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

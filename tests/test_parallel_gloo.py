@@ -1,0 +1,62 @@
+"""Data-parallel path on CPU: 2 gloo ranks.  (i) bucketed gradient all-reduce through GradReducer
+equals the gradient of the global-batch mean loss; (ii) summed integer accuracy counters give the
+same OA / AA as one rank on the concatenated data."""
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import vqa_ref
+
+KW = dict(vq=30, C=11, E=12, Hq=24, Dv=32, A=16, F=16, Hf=8)
+
+
+class _FakeModel:
+    """Stands in for the module's flat gradient storage (the kernels need a GPU; the reducer does not)."""
+
+    def __init__(self, grads, order, cuts):
+        sizes = [grads[k].numel() for k in order]
+        self._flat_grad = torch.cat([grads[k].reshape(-1) for k in order])
+        offs = np.cumsum([0] + sizes)
+        self.buckets = [(int(offs[a]), int(offs[b])) for a, b in zip([0] + cuts, cuts + [len(order)])]
+        self.views = {k: self._flat_grad[offs[i]:offs[i + 1]].view(grads[k].shape) for i, k in enumerate(order)}
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from vqa_amd.parallel import GradReducer, reduce_counters
+    p = vqa_ref.init_params(seed=0, **KW)
+    full = vqa_ref.synthetic_batch(8, 9, KW['Dv'], 7, KW['vq'], KW['C'], seed=4)
+    sl = slice(rank * 4, rank * 4 + 4)
+    _, _, g = vqa_ref.loss_and_grads(p, full['feats'][sl], full['tokens'][sl], full['answers'][sl])
+    order = list(g)
+    fm = _FakeModel(g, order, cuts=[4, 8, len(order) - 1])
+    red = GradReducer()
+    assert red.enabled and red.world == world
+    red.begin(fm)
+    for i in range(len(fm.buckets) - 1):       # the last bucket is left to finish()
+        red.bucket_ready(i)
+    scale = red.finish()
+    _, _, gfull = vqa_ref.loss_and_grads(p, full['feats'], full['tokens'], full['answers'])
+    for k in order:
+        assert torch.allclose(fm.views[k] * scale, gfull[k], rtol=1e-4, atol=1e-7), k
+    # accuracy counters: integer sums
+    logits = vqa_ref.forward(p, full['feats'][sl], full['tokens'][sl])
+    pred = vqa_ref.argmax_first(logits.numpy())
+    c, r = vqa_ref.accuracy_counts(pred, full['answers'][sl].numpy(), full['types'][sl].numpy())
+    counters = reduce_counters(torch.from_numpy(np.concatenate([c, r])))
+    lf = vqa_ref.forward(p, full['feats'], full['tokens'])
+    cf, rf = vqa_ref.accuracy_counts(vqa_ref.argmax_first(lf.numpy()), full['answers'].numpy(), full['types'].numpy())
+    assert np.array_equal(counters.numpy(), np.concatenate([cf, rf]))
+    open(os.path.join(out_dir, f'ok{rank}'), 'w').write('ok')
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_allreduce_and_counters(tmp_path):
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert os.path.exists(tmp_path / 'ok0') and os.path.exists(tmp_path / 'ok1')

@@ -155,6 +155,7 @@ class VQAAttnModel(nn.Module):
         self._shadow_fresh = False
         self._ctx = None
         self.grad_ready_hook = None   # callable(bucket_index) fired as gradient buckets complete
+        self.kernel_events = None     # set to {} to collect per-kernel HIP event pairs
 
     # ------------------------------------------------------------------ flat parameter storage
     def _trainable_order(self) -> List[Tuple[str, nn.Parameter]]:
@@ -347,6 +348,16 @@ class VQAAttnModel(nn.Module):
         if self.grad_ready_hook is not None:
             self.grad_ready_hook(self._bucket_of[name])
 
+    def _event_pair(self, name: str):
+        """When kernel timing is switched on (self.kernel_events = {}), a (start, end) pair of HIP
+        events on the launch stream around one kernel; the start event is recorded here."""
+        if self.kernel_events is None:
+            return None
+        pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        self.kernel_events.setdefault(name, []).append(pair)
+        pair[0].record()
+        return pair
+
     # ------------------------------------------------------------------ forward
     def _prepare_inputs(self, input_v, input_q, captions):
         dev = input_q.device if isinstance(input_q, torch.Tensor) and input_q.is_cuda else input_v.device
@@ -428,9 +439,12 @@ class VQAAttnModel(nn.Module):
             call('vqa_gemm_fused', ptr(feats), Dv, 1, ptr(self._w(pre + 'linear_va.weight')), Dv, 1, ptr(ws[f'P{k}']), A,
                  B * R, A, Dv, ptr(self._f32(pre + 'linear_va.bias')), ptr(ws['inv_norm']), 0, dt, dt, self.gemm_engine)
             self._linear(uT, H, pre + 'linear_qa.weight', pre + 'linear_qa.bias', B, A, H, out_pre=ws[f'qa{k}'], ld_pre=A)
+            ev = self._event_pair('attn_fwd')
             call('vqa_attn_fwd', ptr(ws[f'P{k}']), A, ptr(feats), Dv, ptr(ws[f'qa{k}']), A,
                  ptr(self._f32(pre + 'linear_a.weight')), ptr(self._f32(pre + 'linear_a.bias')), ptr(ws['inv_norm']),
                  ptr(ws[f'p{k}']), ptr(ws[f'pooled{k}']), None, Dv, B, R, A, Dv, dt)
+            if ev is not None:
+                ev[1].record()
             if k + 1 < self.hops:
                 self._linear(ws[f'pooled{k}'], Dv, pre + 'linear_u.weight', pre + 'linear_u.bias', B, H, Dv,
                              addend=u32, ld_add=H, out_pre=ws[f'u32_{k + 1}'], ld_pre=H, out_post=ws[f'uT_{k + 1}'], ld_post=H)
