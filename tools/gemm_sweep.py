@@ -1,0 +1,34 @@
+"""GEMM variant sweep at the step's shapes (development aid, GPU box)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from vqa_amd import _lib
+from vqa_amd._lib import call, ptr
+
+def timeit(fn, n=10, warm=2):
+    for _ in range(warm): fn()
+    torch.cuda.synchronize()
+    s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(n): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / n * 1e3
+
+def run(name, M, N, K, akm, bkm, variants):
+    dt = torch.bfloat16
+    A = (torch.randn((M, K) if akm else (K, M), device='cuda') * 0.5).to(dt)
+    Bm = (torch.randn((N, K) if bkm else (K, N), device='cuda') * 0.5).to(dt)
+    lda = K if akm else M; ldb = K if bkm else N
+    slab = torch.empty(max(v[1] for v in variants) * M * N, device='cuda', dtype=torch.float32)
+    for eng, sk in variants:
+        us = timeit(lambda: call('vqa_gemm_slabs', ptr(A), lda, int(akm), ptr(Bm), ldb, int(bkm), ptr(slab), M * N, N, M, N, K, sk, 1, eng))
+        print(f'{name:12s} M={M:6d} N={N:5d} K={K:6d} tile={"64" if eng == 2 else "128"} splitk={sk:2d}: {us:8.1f} us  {2.0 * M * N * K / us / 1e6:7.1f} TF')
+
+if __name__ == '__main__':
+    run('K4 fwd NT', 50176, 1200, 2048, True, True, [(3, 1), (2, 1)])
+    run('wgrad TN', 1200, 2048, 50176, False, False, [(3, 1), (3, 2), (3, 3), (3, 4), (3, 6), (2, 1), (2, 2)])
+    run('lstm NT', 256, 9600, 2400, True, True, [(3, 1), (3, 2), (3, 3), (3, 4), (2, 1), (2, 2)])
+    run('head NT', 256, 1200, 2048, True, True, [(2, 1), (2, 4), (2, 7), (2, 8), (3, 4), (3, 8)])
+    run('head dgrad', 256, 2048, 1200, True, False, [(2, 1), (2, 4), (3, 4)])
+    run('head wgrad', 1200, 2048, 256, False, False, [(3, 1), (2, 1)])
+    run('xg NT', 3584, 9600, 640, True, True, [(3, 1), (2, 1)])

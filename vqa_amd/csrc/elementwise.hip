@@ -222,14 +222,32 @@ __global__ void k_tanh_drop_bwd(const float* __restrict__ slabs, int nslab, size
     }
 }
 
-// out[n] = sum_m X[m, n]   (bias gradients); deterministic order
+// out[n] = sum_m X[m, n]   (bias gradients); fixed summation order.
+// 256 threads = 8 row groups x 32 columns; each group strides the rows, LDS combines the groups.
 template <typename T>
-__global__ void k_colsum(const T* __restrict__ X, int ld, float* __restrict__ out, int M, int N) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
-    float s = 0.f;
-    for (int m = 0; m < M; ++m) s += to_f32<T>(X[(size_t)m * ld + n]);
-    out[n] = s;
+__global__ void __launch_bounds__(256) k_colsum(const T* __restrict__ X, int ld, float* __restrict__ out, int M, int N) {
+    __shared__ float part[8][33];
+    const int cx = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int n = blockIdx.x * 32 + cx;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (n < N) {
+        int m = rg;
+        for (; m + 24 < M; m += 32) {
+            s0 += to_f32<T>(X[(size_t)m * ld + n]);
+            s1 += to_f32<T>(X[(size_t)(m + 8) * ld + n]);
+            s2 += to_f32<T>(X[(size_t)(m + 16) * ld + n]);
+            s3 += to_f32<T>(X[(size_t)(m + 24) * ld + n]);
+        }
+        for (; m < M; m += 8) s0 += to_f32<T>(X[(size_t)m * ld + n]);
+    }
+    part[rg][cx] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (rg == 0 && n < N) {
+        float s = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) s += part[g][cx];
+        out[n] = s;
+    }
 }
 
 // cast fp32 -> T with row padding: dst[m, 0:N] = src[m, 0:N], dst[m, N:ld_dst] = 0
@@ -498,7 +516,7 @@ int vqa_tanh_dropout_bwd(const float* slabs, int nslab, size_t slab_stride, cons
 
 int vqa_colsum(const void* X, int ld, float* out, int M, int N, int dtype, hipStream_t stream) {
     VQA_REQUIRE(X && out && M >= 0 && N > 0 && ld >= N, "vqa_colsum: bad arguments");
-    DISPATCH_T(dtype, (k_colsum<T><<<(N + 255) / 256, 256, 0, stream>>>((const T*)X, ld, out, M, N)));
+    DISPATCH_T(dtype, (k_colsum<T><<<(N + 31) / 32, 256, 0, stream>>>((const T*)X, ld, out, M, N)));
     return vqa_check_launch("vqa_colsum");
 }
 

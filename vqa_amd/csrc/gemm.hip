@@ -11,11 +11,10 @@
 //     wgrad     dW = dy^T x     A = dy stored [K=batch][M], B = x stored [K=batch][N]
 //
 // bf16 path: 256-thread workgroups, 4 waves in a 2x2 grid, v_mfma_f32_16x16x32_bf16,
-// BK = 64, register-staged global->LDS double buffer (one barrier per K step).
-// k-major tiles sit in LDS as 128-byte rows with the 16-byte chunk index XORed
-// with (row & 7) (conflict-free ds_read_b128 fragments); [K][M] tiles sit as
-// rows of BM*2+32 bytes and are read with ds_read_b64_tr_b16, which hands each
-// lane the k-contiguous fragment the MFMA wants.
+// BK = 64, tiles brought global->LDS by 16-byte LDS-DMA (global_load_lds) into a double
+// buffer, one barrier per K step; a partial last K tile goes through registers with
+// zero fill.  k-major tiles are read back with ds_read_b128, [K][M] tiles with
+// ds_read_b64_tr_b16, which hands each lane the k-contiguous fragment the MFMA wants.
 // fp32 path (the 1e-5 parity mode): a plain LDS-tiled VALU kernel, any strides.
 #include "common.h"
 #include "vqa_hip.h"
@@ -50,18 +49,73 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
 }
 
-template <int ROWS, bool KMAJOR> struct TileGeom;
-template <int ROWS> struct TileGeom<ROWS, true> {      // [ROWS][64] bf16, 128-B rows, XOR swizzle
+// ---- LDS tile images ---------------------------------------------------------------
+// Both images are un-padded so that one wave-wide 16-byte LDS-DMA instruction (1 KiB,
+// lane-linear) fills whole rows; bank conflicts are removed by XOR-ing the 16-byte chunk
+// index with a function of the row, applied to the SOURCE address of the DMA and again
+// on the fragment read.
+//   k-major [ROWS][64]: 128-byte rows, chunk ^= row & 7            (ds_read_b128 fragments)
+//   m-major [64][ROWS]: ROWS*2-byte rows, chunk ^= 2 * f(krow)     (ds_read_b64_tr_b16 fragments;
+//            a half-wave reads k-rows {r..r+3, r+8..r+11}: f spreads them over the 8 32-byte
+//            bank groups)
+template <int ROWS, bool KMAJOR> struct Tile;
+template <int ROWS> struct Tile<ROWS, true> {
     static constexpr int BYTES = ROWS * 128;
-    static constexpr int CHUNKS = ROWS * 8;
+    static constexpr int NI = BYTES / 4096;                 // DMA instructions per wave
+    static __device__ __forceinline__ int swz(int row) { return row & 7; }
+    static __device__ __forceinline__ int off(int row, int c) { return row * 128 + ((c ^ swz(row)) << 4); }
+    // slot (instruction gi, lane) -> tile row and source chunk
+    static __device__ __forceinline__ void slot(int gi, int lane, int& row, int& c) {
+        row = gi * 8 + (lane >> 3);
+        c = (lane & 7) ^ swz(row);
+    }
 };
-template <int ROWS> struct TileGeom<ROWS, false> {     // [64][ROWS] bf16, padded rows
-    static constexpr int STRIDE = ROWS * 2 + 32;
-    static constexpr int BYTES = 64 * STRIDE;
-    static constexpr int CHUNKS = ROWS * 8;
+template <int ROWS> struct Tile<ROWS, false> {
+    static constexpr int RB = ROWS * 2;                     // bytes per k-row
+    static constexpr int CPR = ROWS / 8;                    // chunks per k-row
+    static constexpr int BYTES = 64 * RB;
+    static constexpr int NI = BYTES / 4096;
+    static __device__ __forceinline__ int swz(int krow) {
+        return ROWS == 128 ? (((krow & 3) | (((krow >> 3) & 1) << 2)) << 1)
+                           : ((((krow >> 1) & 1) | (((krow >> 3) & 1) << 1)) << 1);
+    }
+    static __device__ __forceinline__ int off(int krow, int c) { return krow * RB + ((c ^ swz(krow)) << 4); }
+    static __device__ __forceinline__ void slot(int gi, int lane, int& krow, int& c) {
+        constexpr int RPI = 64 / CPR;                       // k-rows per DMA instruction
+        krow = gi * RPI + lane / CPR;
+        c = (lane % CPR) ^ swz(krow);
+    }
 };
 
-// global -> registers for one operand tile (CHUNKS/256 16-byte chunks per thread)
+// Source pointers of this lane's DMA slots for the tile at k = 0 (row / column indices past
+// the operand's extent are clamped: they only feed output rows / columns that are never stored).
+template <int ROWS, bool KMAJOR>
+__device__ __forceinline__ void dma_setup(const bf16_t* __restrict__ X, int ld, int row0, int nrows, int wave, int lane,
+                                          const bf16_t* (&src)[Tile<ROWS, KMAJOR>::NI]) {
+#pragma unroll
+    for (int i = 0; i < Tile<ROWS, KMAJOR>::NI; ++i) {
+        int r, c;
+        Tile<ROWS, KMAJOR>::slot(wave * Tile<ROWS, KMAJOR>::NI + i, lane, r, c);
+        if (KMAJOR) {
+            const int row = min(row0 + r, nrows - 1);
+            src[i] = X + (size_t)row * ld + c * 8;
+        } else {
+            const int col = min(row0 + c * 8, ((nrows - 1) >> 3) << 3);
+            src[i] = X + (size_t)r * ld + col;
+        }
+    }
+}
+
+template <int ROWS, bool KMAJOR>
+__device__ __forceinline__ void dma_issue(const bf16_t* const (&src)[Tile<ROWS, KMAJOR>::NI], size_t koff, char* lds, int wave) {
+    typedef __attribute__((address_space(1))) const void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+#pragma unroll
+    for (int i = 0; i < Tile<ROWS, KMAJOR>::NI; ++i)
+        __builtin_amdgcn_global_load_lds((gptr_t)(src[i] + koff), (lptr_t)(lds + (wave * Tile<ROWS, KMAJOR>::NI + i) * 1024), 16, 0, 0);
+}
+
+// register path (partial K tiles): global -> registers with zero fill, then -> the same LDS image
 template <int ROWS, bool KMAJOR>
 __device__ __forceinline__ void tile_load(const bf16_t* __restrict__ X, int ld, int row0, int nrows, int k0, int kend,
                                           u32x4 (&r)[ROWS / 32]) {
@@ -74,7 +128,7 @@ __device__ __forceinline__ void tile_load(const bf16_t* __restrict__ X, int ld, 
             const int row = row0 + (q >> 3), k = k0 + ((q & 7) << 3);
             if (row < nrows && k < kend) v = *reinterpret_cast<const u32x4*>(X + (size_t)row * ld + k);
         } else {
-            constexpr int CPR = ROWS / 8;                 // chunks per k-row
+            constexpr int CPR = ROWS / 8;
             const int k = k0 + q / CPR, col = row0 + (q % CPR) * 8;
             if (k < kend && col < nrows) v = *reinterpret_cast<const u32x4*>(X + (size_t)k * ld + col);
         }
@@ -89,13 +143,8 @@ __device__ __forceinline__ void tile_store(char* lds, const u32x4 (&r)[ROWS / 32
     for (int i = 0; i < ROWS / 32; ++i) {
         const int q = tid + 256 * i;
         int off;
-        if (KMAJOR) {
-            const int row = q >> 3, c = q & 7;
-            off = row * 128 + ((c ^ (row & 7)) << 4);
-        } else {
-            constexpr int CPR = ROWS / 8;
-            off = (q / CPR) * TileGeom<ROWS, false>::STRIDE + (q % CPR) * 16;
-        }
+        if (KMAJOR) off = Tile<ROWS, true>::off(q >> 3, q & 7);
+        else off = Tile<ROWS, false>::off(q / (ROWS / 8), q % (ROWS / 8));
         *reinterpret_cast<u32x4*>(lds + off) = r[i];
     }
 }
@@ -104,15 +153,16 @@ __device__ __forceinline__ void tile_store(char* lds, const u32x4 (&r)[ROWS / 32
 template <int ROWS, bool KMAJOR>
 __device__ __forceinline__ bf16x8_t frag_read(const char* lds, int r0, int kk, int lane) {
     if (KMAJOR) {
-        const int row = r0 + (lane & 15), c = kk * 4 + (lane >> 4);
-        return *reinterpret_cast<const bf16x8_t*>(lds + row * 128 + ((c ^ (row & 7)) << 4));
+        return *reinterpret_cast<const bf16x8_t*>(lds + Tile<ROWS, true>::off(r0 + (lane & 15), kk * 4 + (lane >> 4)));
     } else {
-        constexpr int S = TileGeom<ROWS, false>::STRIDE;
         const int g = lane >> 4, li = lane & 15;
-        const int off = (kk * 32 + 8 * g + (li >> 2)) * S + (r0 + 4 * (li & 3)) * 2;
+        const int krow = kk * 32 + 8 * g + (li >> 2);
+        const int col = r0 + 4 * (li & 3);
         typedef s16x4_t __attribute__((address_space(3))) * lds_p;
+        // rows krow and krow + 4 have the same swizzle (it ignores bit 2 of the row)
+        const int off = Tile<ROWS, false>::off(krow, col >> 3) + (col & 7) * 2;
         const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(lds + off));
-        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(lds + off + 4 * S));
+        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(lds + off + 4 * Tile<ROWS, false>::RB));
         s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         return __builtin_bit_cast(bf16x8_t, v);
     }
@@ -122,12 +172,14 @@ template <int BM, int BN, bool AKM, bool BKM, class Epi>
 __global__ void __launch_bounds__(256)
 k_gemm_bf16(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, int M, int N, int K,
             int tiles_m, int tiles_n, int k_per_split, Epi epi) {
-    constexpr int A_BYTES = TileGeom<BM, AKM>::BYTES, B_BYTES = TileGeom<BN, BKM>::BYTES;
-    constexpr int STAGE = A_BYTES + B_BYTES;
+    typedef Tile<BM, AKM> TA;
+    typedef Tile<BN, BKM> TB;
+    constexpr int STAGE = TA::BYTES + TB::BYTES;
     constexpr int MT = BM / 32, NT = BN / 32;            // 16x16 tiles per wave in m / n
-    __shared__ __attribute__((aligned(16))) char lds[2 * STAGE];
+    __shared__ __attribute__((aligned(1024))) char lds[2 * STAGE];
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wm = wave >> 1, wn = wave & 1;
     const int L = xcd_remap(blockIdx.x, gridDim.x);
     const int tiles = tiles_m * tiles_n;
     const int split = L / tiles, ti = L % tiles;
@@ -141,21 +193,54 @@ k_gemm_bf16(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B,
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (nk <= 0) {       // an empty K split still owns a slab of zeros
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int n = n0 + wn * (BN / 2) + j * 16 + (lane & 15);
+                const int mb = m0 + wm * (BM / 2) + i * 16 + (lane >> 4) * 4;
+                if (n < N)
+                    for (int r = 0; r < 4; ++r)
+                        if (mb + r < M) epi.store(split, mb + r, n, 0.f);
+            }
+        return;
+    }
+
+    const bf16_t* sa[TA::NI];
+    const bf16_t* sb[TB::NI];
+    dma_setup<BM, AKM>(A, lda, m0, M, wave, lane, sa);
+    dma_setup<BN, BKM>(B, ldb, n0, N, wave, lane, sb);
+    const size_t ka = AKM ? 1 : (size_t)lda, kb = BKM ? 1 : (size_t)ldb;   // elements per unit of k
 
     u32x4 ra[BM / 32], rb[BN / 32];
-    tile_load<BM, AKM>(A, lda, m0, M, kbeg, kend, ra);
-    tile_load<BN, BKM>(B, ldb, n0, N, kbeg, kend, rb);
-    tile_store<BM, AKM>(lds, ra);
-    tile_store<BN, BKM>(lds + A_BYTES, rb);
+    // tile 0
+    if (kbeg + GEMM_BK <= kend) {
+        dma_issue<BM, AKM>(sa, kbeg * ka, lds, wave);
+        dma_issue<BN, BKM>(sb, kbeg * kb, lds + TA::BYTES, wave);
+    } else {
+        tile_load<BM, AKM>(A, lda, m0, M, kbeg, kend, ra);
+        tile_load<BN, BKM>(B, ldb, n0, N, kbeg, kend, rb);
+        tile_store<BM, AKM>(lds, ra);
+        tile_store<BN, BKM>(lds + TA::BYTES, rb);
+    }
     __syncthreads();
 
     for (int it = 0; it < nk; ++it) {
         const char* la = lds + (it & 1) * STAGE;
-        const char* lb = la + A_BYTES;
+        const char* lb = la + TA::BYTES;
+        char* nx = lds + ((it + 1) & 1) * STAGE;
+        const int kn = kbeg + (it + 1) * GEMM_BK;
         const bool more = it + 1 < nk;
+        const bool full = kn + GEMM_BK <= kend;
         if (more) {
-            tile_load<BM, AKM>(A, lda, m0, M, kbeg + (it + 1) * GEMM_BK, kend, ra);
-            tile_load<BN, BKM>(B, ldb, n0, N, kbeg + (it + 1) * GEMM_BK, kend, rb);
+            if (full) {
+                dma_issue<BM, AKM>(sa, kn * ka, nx, wave);
+                dma_issue<BN, BKM>(sb, kn * kb, nx + TA::BYTES, wave);
+            } else {
+                tile_load<BM, AKM>(A, lda, m0, M, kn, kend, ra);
+                tile_load<BN, BKM>(B, ldb, n0, N, kn, kend, rb);
+            }
         }
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -164,16 +249,17 @@ k_gemm_bf16(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B,
             for (int i = 0; i < MT; ++i) fa[i] = frag_read<BM, AKM>(la, wm * (BM / 2) + i * 16, kk, lane);
 #pragma unroll
             for (int j = 0; j < NT; ++j) fb[j] = frag_read<BN, BKM>(lb, wn * (BN / 2) + j * 16, kk, lane);
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
         }
-        if (more) {
-            char* nx = lds + ((it + 1) & 1) * STAGE;
+        if (more && !full) {
             tile_store<BM, AKM>(nx, ra);
-            tile_store<BN, BKM>(nx + A_BYTES, rb);
+            tile_store<BN, BKM>(nx + TA::BYTES, rb);
         }
         __syncthreads();
     }
@@ -245,12 +331,21 @@ k_gemm_valu(const T* __restrict__ A, int lda, const T* __restrict__ B, int ldb, 
 // ---- host side ----------------------------------------------------------------------
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// tile choice shared by the launcher and the split-K hint: 128x128 workgroup tiles when the
+// output has enough of them, 64x64 otherwise; engine 2 / 3 force 64 / 128
+static inline int pick_tile(int M, int N, int engine) {
+    if (engine == 2) return 64;
+    if (engine == 3) return 128;
+    const long t128 = (long)ceil_div(M, 128) * ceil_div(N, 128);
+    return (M > 64 && N > 64 && t128 >= 40) ? 128 : 64;
+}
+
 template <class Epi>
 static int launch_bf16(const void* A, int lda, int akm, const void* B, int ldb, int bkm, int M, int N, int K,
-                       int splitk, const Epi& epi, hipStream_t stream) {
+                       int splitk, int engine, const Epi& epi, hipStream_t stream) {
     int kps = ceil_div(ceil_div(K, splitk), GEMM_BK) * GEMM_BK;
-    const bool big = (long)ceil_div(M, 128) * ceil_div(N, 128) * splitk >= 192;
-    const int bm = big ? 128 : 64;
+    const int bm = pick_tile(M, N, engine);
+    const bool big = bm == 128;
     const int tm = ceil_div(M, bm), tn = ceil_div(N, bm);
     const unsigned grid = (unsigned)(tm * tn * splitk);
     const bf16_t* a = (const bf16_t*)A; const bf16_t* b = (const bf16_t*)B;
@@ -291,7 +386,7 @@ static int gemm_check(const void* A, int lda, int akm, const void* B, int ldb, i
     VQA_REQUIRE(M > 0 && N > 0 && K > 0, "vqa_gemm: M, N, K must be positive");
     VQA_REQUIRE(dtype == VQA_F32 || dtype == VQA_BF16, "vqa_gemm: dtype");
     VQA_REQUIRE(lda >= (akm ? K : M) && ldb >= (bkm ? K : N), "vqa_gemm: leading dimension smaller than the row");
-    if (dtype == VQA_BF16 && engine == 0) {
+    if (dtype == VQA_BF16 && engine != 1) {
         // the MFMA path moves 16-byte chunks: 8-element granularity on the contiguous index
         VQA_REQUIRE(lda % 8 == 0 && ldb % 8 == 0, "vqa_gemm: bf16 leading dimensions must be multiples of 8");
         VQA_REQUIRE((((uintptr_t)A | (uintptr_t)B) & 15) == 0, "vqa_gemm: bf16 operands must be 16-byte aligned");
@@ -303,12 +398,13 @@ static int gemm_check(const void* A, int lda, int akm, const void* B, int ldb, i
 
 extern "C" {
 
-// K splits that give roughly one to two workgroups per CU for small-M products
+// K splits that give about two workgroups per CU for products with few output tiles,
+// keeping at least 4 (128-tile) / 4 (64-tile) K steps of 64 per split
 int vqa_gemm_splitk_hint(int M, int N, int K) {
-    const long t64 = (long)ceil_div(M, 64) * ceil_div(N, 64);
-    if (t64 >= 256) return 1;
-    int s = (int)((384 + t64 - 1) / t64);
-    const int maxs = K / 256 > 0 ? K / 256 : 1;          // keep >= 4 K steps per split
+    const int bm = pick_tile(M, N, 0);
+    const long tiles = (long)ceil_div(M, bm) * ceil_div(N, bm);
+    int s = (int)(512 / tiles);                 // at most two workgroups per CU in one round
+    const int maxs = K / 256 > 0 ? K / 256 : 1;
     if (s > maxs) s = maxs;
     if (s > 32) s = 32;
     return s < 1 ? 1 : s;
@@ -321,7 +417,7 @@ int vqa_gemm_slabs(const void* A, int lda, int a_kmajor, const void* B, int ldb,
     VQA_REQUIRE(slabs && splitk >= 1 && splitk <= 64 && ld_slab >= N, "vqa_gemm_slabs: bad slab arguments");
     VQA_REQUIRE(splitk == 1 || slab_stride >= (size_t)M * ld_slab, "vqa_gemm_slabs: slab_stride too small");
     EpiSlab epi{slabs, slab_stride, ld_slab};
-    if (dtype == VQA_BF16 && engine == 0) launch_bf16(A, lda, a_kmajor, B, ldb, b_kmajor, M, N, K, splitk, epi, stream);
+    if (dtype == VQA_BF16 && engine != 1) launch_bf16(A, lda, a_kmajor, B, ldb, b_kmajor, M, N, K, splitk, engine, epi, stream);
     else if (dtype == VQA_BF16) launch_valu<bf16_t>(A, lda, a_kmajor, B, ldb, b_kmajor, M, N, K, splitk, epi, stream);
     else launch_valu<float>(A, lda, a_kmajor, B, ldb, b_kmajor, M, N, K, splitk, epi, stream);
     return vqa_check_launch("vqa_gemm_slabs");
@@ -335,7 +431,7 @@ int vqa_gemm_fused(const void* A, int lda, int a_kmajor, const void* B, int ldb,
     VQA_REQUIRE(act == 0 || act == 1, "vqa_gemm_fused: act must be 0 (none) or 1 (tanh)");
     VQA_REQUIRE(out_dtype == VQA_F32 || out_dtype == VQA_BF16, "vqa_gemm_fused: out_dtype");
     EpiFused epi{C, ldc, bias, row_scale, act, out_dtype == VQA_BF16};
-    if (dtype == VQA_BF16 && engine == 0) launch_bf16(A, lda, a_kmajor, B, ldb, b_kmajor, M, N, K, 1, epi, stream);
+    if (dtype == VQA_BF16 && engine != 1) launch_bf16(A, lda, a_kmajor, B, ldb, b_kmajor, M, N, K, 1, engine, epi, stream);
     else if (dtype == VQA_BF16) launch_valu<bf16_t>(A, lda, a_kmajor, B, ldb, b_kmajor, M, N, K, 1, epi, stream);
     else launch_valu<float>(A, lda, a_kmajor, B, ldb, b_kmajor, M, N, K, 1, epi, stream);
     return vqa_check_launch("vqa_gemm_fused");
