@@ -25,21 +25,22 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 #define GEMM_BK 64
 
-// ---- epilogues ----------------------------------------------------------------
-struct EpiSlab {          // fp32 partial sums, one slab per K split
-    float* out; size_t slab_stride; int ld;
-    __device__ __forceinline__ void store(int split, int m, int n, float v) const {
-        out[split * slab_stride + (size_t)m * ld + n] = v;
-    }
-};
-struct EpiFused {         // v = act(row_scale[m] * acc + bias[n]); out fp32 or bf16
-    void* out; int ld; const float* bias; const float* row_scale; int act; int out_bf16;
-    __device__ __forceinline__ void store(int, int m, int n, float v) const {
-        if (row_scale) v *= row_scale[m];
-        if (bias) v += bias[n];
+// ---- epilogue ------------------------------------------------------------------
+// v = act(row_scale[m] * acc + bias[n]) written as fp32 or bf16 at out + split * split_stride.
+// A split-K launch writes plain fp32 partial sums (one slab per split).
+struct Epi {
+    void* out; int ld; int out_bf16; size_t split_stride;
+    const float* bias; const float* row_scale; int act;
+    __device__ __forceinline__ float value(float v, float rs, float b) const {
+        v = v * rs + b;
         if (act == 1) v = out_bf16 ? fast_tanh(v) : tanhf(v);
-        if (out_bf16) ((bf16_t*)out)[(size_t)m * ld + n] = f32_to_bf16(v);
-        else ((float*)out)[(size_t)m * ld + n] = v;
+        return v;
+    }
+    // scalar store (VALU kernel and unaligned tails)
+    __device__ __forceinline__ void store(int split, int m, int n, float v) const {
+        v = value(v, row_scale ? row_scale[m] : 1.f, bias ? bias[n] : 0.f);
+        if (out_bf16) ((bf16_t*)out)[split * split_stride + (size_t)m * ld + n] = f32_to_bf16(v);
+        else ((float*)out)[split * split_stride + (size_t)m * ld + n] = v;
     }
 };
 
@@ -168,7 +169,86 @@ __device__ __forceinline__ bf16x8_t frag_read(const char* lds, int r0, int kk, i
     }
 }
 
-template <int BM, int BN, bool AKM, bool BKM, class Epi>
+// Accumulators -> global through LDS so that every store instruction writes whole 64..256-byte
+// row segments.  Each wave stages 32 rows of its (BM/2 x BN/2) tile at a time as fp32.
+template <int BM, int BN>
+__device__ __forceinline__ void epilogue_store(char* lds, f32x4 (&acc)[BM / 32][BN / 32], const Epi& epi, int split,
+                                               int m_w, int n_w, int M, int N, int wave, int lane) {
+    constexpr int MT = BM / 32, NT = BN / 32, WN = BN / 2, LDW = WN + 4;
+    float* wl = reinterpret_cast<float*>(lds) + wave * (32 * LDW);
+    float bias[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int n = n_w + j * 16 + (lane & 15);
+        bias[j] = (epi.bias && n < N) ? epi.bias[n] : 0.f;
+    }
+    const bool vec_ok = ((((size_t)epi.ld * (epi.out_bf16 ? 2 : 4)) & 15) == 0) && ((((uintptr_t)epi.out) & 15) == 0) &&
+                        (((epi.split_stride * 4) & 15) == 0);
+#pragma unroll
+    for (int pass = 0; pass < MT / 2; ++pass) {
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+            const int i = pass * 2 + ii;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rl = ii * 16 + (lane >> 4) * 4 + r;
+                const int m = m_w + pass * 32 + rl;
+                const float rs = (epi.row_scale && m < M) ? epi.row_scale[m] : 1.f;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) wl[rl * LDW + j * 16 + (lane & 15)] = epi.value(acc[i][j][r], rs, bias[j]);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (epi.out_bf16) {
+            bf16_t* out = (bf16_t*)epi.out;
+            constexpr int CPR = WN / 8;                       // 16-byte chunks per row
+#pragma unroll
+            for (int it = 0; it < 32 * CPR / 64; ++it) {
+                const int q = it * 64 + lane, rl = q / CPR, c = (q % CPR) * 8;
+                const int m = m_w + pass * 32 + rl, n = n_w + c;
+                if (m >= M || n >= N) continue;
+                const f32x4 a = *reinterpret_cast<const f32x4*>(wl + rl * LDW + c);
+                const f32x4 b = *reinterpret_cast<const f32x4*>(wl + rl * LDW + c + 4);
+                bf16_t* dst = out + (size_t)m * epi.ld + n;
+                if (vec_ok && n + 8 <= N) {
+                    u16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { o[e] = f32_to_bf16(a[e]); o[4 + e] = f32_to_bf16(b[e]); }
+                    *reinterpret_cast<u16x8*>(dst) = o;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (n + e < N) dst[e] = f32_to_bf16(a[e]);
+                        if (n + 4 + e < N) dst[4 + e] = f32_to_bf16(b[e]);
+                    }
+                }
+            }
+        } else {
+            float* out = (float*)epi.out + split * epi.split_stride;
+            constexpr int CPR = WN / 4;
+#pragma unroll
+            for (int it = 0; it < 32 * CPR / 64; ++it) {
+                const int q = it * 64 + lane, rl = q / CPR, c = (q % CPR) * 4;
+                const int m = m_w + pass * 32 + rl, n = n_w + c;
+                if (m >= M || n >= N) continue;
+                const f32x4 a = *reinterpret_cast<const f32x4*>(wl + rl * LDW + c);
+                float* dst = out + (size_t)m * epi.ld + n;
+                if (vec_ok && n + 4 <= N) {
+                    *reinterpret_cast<f32x4*>(dst) = a;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < N) dst[e] = a[e];
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <int BM, int BN, bool AKM, bool BKM>
 __global__ void __launch_bounds__(256)
 k_gemm_bf16(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, int M, int N, int K,
             int tiles_m, int tiles_n, int k_per_split, Epi epi) {
@@ -176,7 +256,9 @@ k_gemm_bf16(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B,
     typedef Tile<BN, BKM> TB;
     constexpr int STAGE = TA::BYTES + TB::BYTES;
     constexpr int MT = BM / 32, NT = BN / 32;            // 16x16 tiles per wave in m / n
-    __shared__ __attribute__((aligned(1024))) char lds[2 * STAGE];
+    constexpr int EPI_BYTES = 4 * 32 * (BN / 2 + 4) * 4;
+    constexpr int LDS_BYTES = 2 * STAGE > EPI_BYTES ? 2 * STAGE : EPI_BYTES;
+    __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wm = wave >> 1, wn = wave & 1;
@@ -186,26 +268,13 @@ k_gemm_bf16(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B,
     const int m0 = (ti / tiles_n) * BM, n0 = (ti % tiles_n) * BN;
     const int kbeg = split * k_per_split;
     const int kend = min(K, kbeg + k_per_split);
-    const int nk = (kend - kbeg + GEMM_BK - 1) / GEMM_BK;
+    const int nk = kend > kbeg ? (kend - kbeg + GEMM_BK - 1) / GEMM_BK : 0;    // an empty split stores zeros
 
     f32x4 acc[MT][NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (nk <= 0) {       // an empty K split still owns a slab of zeros
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int n = n0 + wn * (BN / 2) + j * 16 + (lane & 15);
-                const int mb = m0 + wm * (BM / 2) + i * 16 + (lane >> 4) * 4;
-                if (n < N)
-                    for (int r = 0; r < 4; ++r)
-                        if (mb + r < M) epi.store(split, mb + r, n, 0.f);
-            }
-        return;
-    }
 
     const bf16_t* sa[TA::NI];
     const bf16_t* sb[TB::NI];
@@ -214,15 +283,16 @@ k_gemm_bf16(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B,
     const size_t ka = AKM ? 1 : (size_t)lda, kb = BKM ? 1 : (size_t)ldb;   // elements per unit of k
 
     u32x4 ra[BM / 32], rb[BN / 32];
-    // tile 0
-    if (kbeg + GEMM_BK <= kend) {
-        dma_issue<BM, AKM>(sa, kbeg * ka, lds, wave);
-        dma_issue<BN, BKM>(sb, kbeg * kb, lds + TA::BYTES, wave);
-    } else {
-        tile_load<BM, AKM>(A, lda, m0, M, kbeg, kend, ra);
-        tile_load<BN, BKM>(B, ldb, n0, N, kbeg, kend, rb);
-        tile_store<BM, AKM>(lds, ra);
-        tile_store<BN, BKM>(lds + TA::BYTES, rb);
+    if (nk > 0) {                                        // tile 0
+        if (kbeg + GEMM_BK <= kend) {
+            dma_issue<BM, AKM>(sa, kbeg * ka, lds, wave);
+            dma_issue<BN, BKM>(sb, kbeg * kb, lds + TA::BYTES, wave);
+        } else {
+            tile_load<BM, AKM>(A, lda, m0, M, kbeg, kend, ra);
+            tile_load<BN, BKM>(B, ldb, n0, N, kbeg, kend, rb);
+            tile_store<BM, AKM>(lds, ra);
+            tile_store<BN, BKM>(lds + TA::BYTES, rb);
+        }
     }
     __syncthreads();
 
@@ -242,20 +312,23 @@ k_gemm_bf16(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B,
                 tile_load<BN, BKM>(B, ldb, n0, N, kn, kend, rb);
             }
         }
+        // all fragment reads of the K step are issued first; the MFMAs of sub-step 0 run
+        // while the reads of sub-step 1 are still landing
+        bf16x8_t fa[2][MT], fb[2][NT];
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            bf16x8_t fa[MT], fb[NT];
 #pragma unroll
-            for (int i = 0; i < MT; ++i) fa[i] = frag_read<BM, AKM>(la, wm * (BM / 2) + i * 16, kk, lane);
+            for (int i = 0; i < MT; ++i) fa[kk][i] = frag_read<BM, AKM>(la, wm * (BM / 2) + i * 16, kk, lane);
 #pragma unroll
-            for (int j = 0; j < NT; ++j) fb[j] = frag_read<BN, BKM>(lb, wn * (BN / 2) + j * 16, kk, lane);
-            __builtin_amdgcn_s_setprio(1);
+            for (int j = 0; j < NT; ++j) fb[kk][j] = frag_read<BN, BKM>(lb, wn * (BN / 2) + j * 16, kk, lane);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[kk][i], fb[kk][j], acc[i][j], 0, 0, 0);
         }
         if (more && !full) {
             tile_store<BM, AKM>(nx, ra);
@@ -264,23 +337,11 @@ k_gemm_bf16(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B,
         __syncthreads();
     }
 
-    // C fragment: col = lane & 15, row = (lane >> 4) * 4 + reg
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int n = n0 + wn * (BN / 2) + j * 16 + (lane & 15);
-            const int mb = m0 + wm * (BM / 2) + i * 16 + (lane >> 4) * 4;
-            if (n < N) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (mb + r < M) epi.store(split, mb + r, n, acc[i][j][r]);
-            }
-        }
+    epilogue_store<BM, BN>(lds, acc, epi, split, m0 + wm * (BM / 2), n0 + wn * (BN / 2), M, N, wave, lane);
 }
 
 // ---- fp32 / any-stride VALU kernel -----------------------------------------------
-template <typename T, bool AKM, bool BKM, class Epi>
+template <typename T, bool AKM, bool BKM>
 __global__ void __launch_bounds__(256)
 k_gemm_valu(const T* __restrict__ A, int lda, const T* __restrict__ B, int ldb, int M, int N, int K,
             int tiles_m, int tiles_n, int k_per_split, Epi epi) {
@@ -340,7 +401,6 @@ static inline int pick_tile(int M, int N, int engine) {
     return (M > 64 && N > 64 && t128 >= 40) ? 128 : 64;
 }
 
-template <class Epi>
 static int launch_bf16(const void* A, int lda, int akm, const void* B, int ldb, int bkm, int M, int N, int K,
                        int splitk, int engine, const Epi& epi, hipStream_t stream) {
     int kps = ceil_div(ceil_div(K, splitk), GEMM_BK) * GEMM_BK;
@@ -350,7 +410,7 @@ static int launch_bf16(const void* A, int lda, int akm, const void* B, int ldb, 
     const unsigned grid = (unsigned)(tm * tn * splitk);
     const bf16_t* a = (const bf16_t*)A; const bf16_t* b = (const bf16_t*)B;
 #define LAUNCH(BMV, AK, BK_)                                                                         \
-    k_gemm_bf16<BMV, BMV, AK, BK_, Epi><<<grid, 256, 0, stream>>>(a, lda, b, ldb, M, N, K, tm, tn, kps, epi)
+    k_gemm_bf16<BMV, BMV, AK, BK_><<<grid, 256, 0, stream>>>(a, lda, b, ldb, M, N, K, tm, tn, kps, epi)
     if (big) {
         if (akm && bkm) LAUNCH(128, true, true);
         else if (akm && !bkm) LAUNCH(128, true, false);
@@ -366,17 +426,17 @@ static int launch_bf16(const void* A, int lda, int akm, const void* B, int ldb, 
     return 0;
 }
 
-template <typename T, class Epi>
+template <typename T>
 static int launch_valu(const void* A, int lda, int akm, const void* B, int ldb, int bkm, int M, int N, int K,
                        int splitk, const Epi& epi, hipStream_t stream) {
     const int kps = ceil_div(ceil_div(K, splitk), 16) * 16;
     const int tm = ceil_div(M, 64), tn = ceil_div(N, 64);
     const unsigned grid = (unsigned)(tm * tn * splitk);
     const T* a = (const T*)A; const T* b = (const T*)B;
-    if (akm && bkm) k_gemm_valu<T, true, true, Epi><<<grid, 256, 0, stream>>>(a, lda, b, ldb, M, N, K, tm, tn, kps, epi);
-    else if (akm && !bkm) k_gemm_valu<T, true, false, Epi><<<grid, 256, 0, stream>>>(a, lda, b, ldb, M, N, K, tm, tn, kps, epi);
-    else if (!akm && bkm) k_gemm_valu<T, false, true, Epi><<<grid, 256, 0, stream>>>(a, lda, b, ldb, M, N, K, tm, tn, kps, epi);
-    else k_gemm_valu<T, false, false, Epi><<<grid, 256, 0, stream>>>(a, lda, b, ldb, M, N, K, tm, tn, kps, epi);
+    if (akm && bkm) k_gemm_valu<T, true, true><<<grid, 256, 0, stream>>>(a, lda, b, ldb, M, N, K, tm, tn, kps, epi);
+    else if (akm && !bkm) k_gemm_valu<T, true, false><<<grid, 256, 0, stream>>>(a, lda, b, ldb, M, N, K, tm, tn, kps, epi);
+    else if (!akm && bkm) k_gemm_valu<T, false, true><<<grid, 256, 0, stream>>>(a, lda, b, ldb, M, N, K, tm, tn, kps, epi);
+    else k_gemm_valu<T, false, false><<<grid, 256, 0, stream>>>(a, lda, b, ldb, M, N, K, tm, tn, kps, epi);
     return 0;
 }
 
@@ -416,7 +476,7 @@ int vqa_gemm_slabs(const void* A, int lda, int a_kmajor, const void* B, int ldb,
     if (int rc = gemm_check(A, lda, a_kmajor, B, ldb, b_kmajor, M, N, K, dtype, engine)) return rc;
     VQA_REQUIRE(slabs && splitk >= 1 && splitk <= 64 && ld_slab >= N, "vqa_gemm_slabs: bad slab arguments");
     VQA_REQUIRE(splitk == 1 || slab_stride >= (size_t)M * ld_slab, "vqa_gemm_slabs: slab_stride too small");
-    EpiSlab epi{slabs, slab_stride, ld_slab};
+    Epi epi{slabs, ld_slab, 0, slab_stride, nullptr, nullptr, 0};
     if (dtype == VQA_BF16 && engine != 1) launch_bf16(A, lda, a_kmajor, B, ldb, b_kmajor, M, N, K, splitk, engine, epi, stream);
     else if (dtype == VQA_BF16) launch_valu<bf16_t>(A, lda, a_kmajor, B, ldb, b_kmajor, M, N, K, splitk, epi, stream);
     else launch_valu<float>(A, lda, a_kmajor, B, ldb, b_kmajor, M, N, K, splitk, epi, stream);
@@ -430,7 +490,7 @@ int vqa_gemm_fused(const void* A, int lda, int a_kmajor, const void* B, int ldb,
     VQA_REQUIRE(C && ldc >= N, "vqa_gemm_fused: bad output");
     VQA_REQUIRE(act == 0 || act == 1, "vqa_gemm_fused: act must be 0 (none) or 1 (tanh)");
     VQA_REQUIRE(out_dtype == VQA_F32 || out_dtype == VQA_BF16, "vqa_gemm_fused: out_dtype");
-    EpiFused epi{C, ldc, bias, row_scale, act, out_dtype == VQA_BF16};
+    Epi epi{C, ldc, out_dtype == VQA_BF16, 0, bias, row_scale, act};
     if (dtype == VQA_BF16 && engine != 1) launch_bf16(A, lda, a_kmajor, B, ldb, b_kmajor, M, N, K, 1, engine, epi, stream);
     else if (dtype == VQA_BF16) launch_valu<bf16_t>(A, lda, a_kmajor, B, ldb, b_kmajor, M, N, K, 1, epi, stream);
     else launch_valu<float>(A, lda, a_kmajor, B, ldb, b_kmajor, M, N, K, 1, epi, stream);
