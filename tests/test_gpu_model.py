@@ -247,3 +247,30 @@ def test_softmax_ce_fixture(golden_dir):
     assert abs(float(out) - float(z['loss'])) <= 1e-6 * abs(float(z['loss']))
     assert rel_err(dl[:, :C], torch.from_numpy(z['dlogits'])) <= 1e-6
     assert float(dl[:, C:].abs().max()) == 0.0
+
+
+def test_train_driver_synthetic(tmp_path):
+    """The reference-CLI driver on synthetic data: loss falls, checkpoints carry the reference key names and
+    reload into a fresh module giving identical logits."""
+    from vqa_amd import train as drv
+    from vqa_amd.model import VQAAttnModel
+    import argparse
+    args = argparse.Namespace(model='VQAAttnModel', gpu=0)
+    dev = torch.device('cuda:0')
+    kw = dict(emb_size=20, question_out=48, visual_out=64, attention_dim=40, fusion_in=32, fusion_hidden=16)
+    tr = drv.SynthVQADataset(4, 32, 16, 64, 8, 50, 21, dev, seed=1)
+    va = drv.SynthVQADataset(1, 32, 16, 64, 8, 50, 21, dev, seed=2)
+    m = VQAAttnModel(['w'] * 50, ['a'] * 21, args, dtype=torch.float32, dropout=0.0, **kw).to(dev)
+    hist = drv.train(m, tr, va, 6, 3e-3, args, out_dir=str(tmp_path))
+    assert hist[-1]['train_loss'] < hist[0]['train_loss']
+    sd = torch.load(tmp_path / 'ModelRunningRSVQA_VQAAttnModel.pth', weights_only=True)
+    assert 'linear_classif2.weight' in sd and 'seq2vec.rnn.weight_hh_l0' in sd
+    m2 = VQAAttnModel(['w'] * 50, ['a'] * 21, args, dtype=torch.float32, dropout=0.0, seed=99, **kw)
+    m2.load_state_dict(sd)
+    m2 = m2.to(dev).eval()
+    m.eval()
+    q, a, f, t = va.batches[0]
+    with torch.no_grad():
+        assert torch.equal(m(f, q), m2(f, q))
+    counts = hist[-1]['val']['count']
+    assert sum(counts.values()) == 32

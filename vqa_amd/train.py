@@ -1,0 +1,116 @@
+"""Training / evaluation driver with the reference's command line
+(vqa_model/train.py:241-252, vqa_model/test.py:119-128):
+
+    python -m vqa_amd.train --model VQAAttnModel --dataset SYNTH --epochs 2 --bs 256 --gpu 0
+
+Same epoch structure as the reference (validation first, then training, train.py:48-228): per-epoch
+validation loss / OA / AA, running training loss = sum(loss * B) / len(dataset), best-on-validation and
+running checkpoints under the reference's file names.  ``--dataset SYNTH`` uses device-resident synthetic
+VQA-v2-shaped data (precomputed region features); the LR / HR datasets of the reference need image files
+and a feature extractor that are outside this package.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+
+import torch
+
+from .metrics import AccuracyMeter, HR_TYPES
+from .model import VQAAttnModel
+from .parallel import GradReducer
+
+
+class SynthVQADataset:
+    """Synthetic stand-in for VQALoader: batches of (question int64 (B,L), answer int64 (B,),
+    feats (B,R,Dv), type ids) already on the device (tuple order of VQALoader.py:176)."""
+
+    def __init__(self, n_batches, B, R, Dv, L, Vq, C, device, seed, dtype=torch.bfloat16):
+        g = torch.Generator(device=device).manual_seed(seed)
+        self.batches = []
+        for _ in range(n_batches):
+            feats = torch.randn((B, R, Dv), device=device, generator=g).clamp_min_(0).to(dtype)
+            lens = torch.randint(3, L + 1, (B,), device=device, generator=g)
+            tok = torch.randint(1, Vq + 1, (B, L), device=device, generator=g)
+            tok = torch.where(torch.arange(L, device=device)[None, :] < (lens[:, None] - 1), tok, torch.zeros_like(tok))
+            # learnable synthetic rule so that the loss visibly falls: the answer is a function of two tokens
+            ans = (tok[:, 0] * 7 + tok[:, 1] * 13) % C
+            types = torch.randint(0, 4, (B,), device=device, generator=g, dtype=torch.int32)
+            self.batches.append((tok, ans, feats, types))
+        self.B = B
+
+    def __len__(self):
+        return len(self.batches) * self.B
+
+    def __iter__(self):
+        return iter(self.batches)
+
+
+def evaluate(model, dataset, meter):
+    """One no-grad pass: mean loss over the dataset, per-type accuracy, OA, AA (train.py:50-161)."""
+    model.eval()
+    meter.reset()
+    running = torch.zeros(1, device=meter.counters.device)
+    with torch.no_grad():
+        for question, answer, image, types in dataset:
+            model._forward_impl(*model._prepare_inputs(image, question, None))
+            running += model.loss_and_grad_logits(answer) * question.shape[0]
+            meter.update(model, answer, types)
+    res = meter.result()
+    res['loss'] = float(running) / len(dataset)
+    return res
+
+
+def train(model, train_dataset, validate_dataset, num_epochs, learning_rate, args, Dataset='SYNTH', out_dir=None):
+    meter = AccuracyMeter(HR_TYPES, device=next(model.parameters()).device)
+    reducer = GradReducer()
+    min_val, best_epoch, history = float('inf'), 0, []
+    for epoch in range(num_epochs):
+        print('Epoch Number:', epoch)
+        val = evaluate(model, validate_dataset, meter)
+        print('epoch #%d val loss: %.3f' % (epoch, val['loss']))
+        print('epoch #%d OA: %.3f' % (epoch, val['OA']))
+        print('epoch #%d AA: %.3f' % (epoch, val['AA']))
+        model.train()
+        running = torch.zeros(1, device=meter.counters.device)
+        for question, answer, image, _ in train_dataset:
+            loss = model.train_step(image, question, answer, lr=learning_rate, reducer=reducer)
+            running += loss * question.shape[0]
+        train_loss = float(running) / len(train_dataset)
+        print('epoch #%d loss: %.3f' % (epoch, train_loss))
+        history.append({'val': val, 'train_loss': train_loss})
+        if out_dir:
+            os.makedirs(out_dir, exist_ok=True)
+            if val['loss'] < min_val:
+                min_val, best_epoch = val['loss'], epoch
+                torch.save(model.state_dict(), f'{out_dir}/ModelBestRSVQA_{args.model}.pth')
+            torch.save(model.state_dict(), f'{out_dir}/ModelRunningRSVQA_{args.model}.pth')
+    return history
+
+
+def main(argv=None):
+    parser = argparse.ArgumentParser(description='MI355X VQA training')
+    parser.add_argument('--bs', type=int, default=40)
+    parser.add_argument('--gpu', type=int, default=0)
+    parser.add_argument('--epochs', type=int, default=150)
+    parser.add_argument('--lr', type=float, default=0.00001)
+    parser.add_argument('--model', type=str, required=True)
+    parser.add_argument('--dataset', type=str, required=True)
+    parser.add_argument('--out', type=str, default=None, help='checkpoint directory (reference: ../data/dump-models/<dataset>)')
+    args = parser.parse_args(argv)
+    if args.model != 'VQAAttnModel':
+        raise SystemExit('only --model VQAAttnModel is built on this path')
+    if args.dataset != 'SYNTH':
+        raise SystemExit('only --dataset SYNTH is available (LR / HR need image files and a feature extractor)')
+    dev = torch.device(f'cuda:{args.gpu}')
+    torch.cuda.set_device(dev)
+    Vq, C, L, R, Dv = 10000, 3000, 14, 196, 2048
+    train_ds = SynthVQADataset(8, args.bs, R, Dv, L, Vq, C, dev, seed=42)
+    val_ds = SynthVQADataset(2, args.bs, R, Dv, L, Vq, C, dev, seed=43)
+    model = VQAAttnModel(['<EOS>'] + [f'w{i}' for i in range(Vq - 1)], ['<EOS>'] + [f'a{i}' for i in range(C - 1)],
+                         args).to(dev)
+    return train(model, train_ds, val_ds, args.epochs, args.lr, args, args.dataset, args.out)
+
+
+if __name__ == '__main__':
+    main()
