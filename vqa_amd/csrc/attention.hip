@@ -283,6 +283,327 @@ k_attn_bwd(const T* __restrict__ P, int ldP, const T* __restrict__ V, int ldV, c
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// Pipelined variants (the ones the bench shapes run): same arithmetic and summation
+// order as the kernels above, with the loads of the next region row issued before the
+// current one is consumed so that every wave always has HBM requests in flight.
+// NVA = ceil(A / 512), NVD = ceil(Dv / 512): 16-byte vectors per lane per row.
+// Requirements (checked by the launcher): Dv / 8 <= ATT_THREADS, NVA, NVD <= 4.
+// ---------------------------------------------------------------------------
+template <typename T> struct RawVec;
+template <> struct RawVec<bf16_t> {
+    typedef u16x8 type;
+    static __device__ __forceinline__ type load(const bf16_t* p) { return *reinterpret_cast<const u16x8*>(p); }
+    static __device__ __forceinline__ type zero() { return u16x8{0, 0, 0, 0, 0, 0, 0, 0}; }
+    static __device__ __forceinline__ float get(const type& v, int i) { return bf16_to_f32(v[i]); }
+};
+template <> struct RawVec<float> {
+    struct type { f32x4 a, b; };
+    static __device__ __forceinline__ type load(const float* p) {
+        type t; t.a = *reinterpret_cast<const f32x4*>(p); t.b = *reinterpret_cast<const f32x4*>(p + 4); return t;
+    }
+    static __device__ __forceinline__ type zero() { type t; t.a = f32x4{0, 0, 0, 0}; t.b = f32x4{0, 0, 0, 0}; return t; }
+    static __device__ __forceinline__ float get(const type& v, int i) { return i < 4 ? v.a[i] : v.b[i - 4]; }
+};
+
+// 16-byte streaming load that does not allocate in the caches (each byte is used once)
+__device__ __forceinline__ u16x8 ld_stream(const bf16_t* p) {
+    return __builtin_nontemporal_load(reinterpret_cast<const u16x8*>(p));
+}
+__device__ __forceinline__ float bf16_lo(unsigned int w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned int w) { return __uint_as_float(w & 0xffff0000u); }
+
+// bf16 only.  Score phase arithmetic per element: y = P*k + qa*k (k = 2 log2 e), e = exp2(y),
+// r = 1/(e+1); tanh = 1 - 2r, so  w.tanh = sum(w) - sum(2w r): one conversion, two FMAs, one add and
+// two transcendentals per element.
+template <int NVA>
+__global__ void __launch_bounds__(ATT_THREADS)
+k_attn_fwd_pipe(const bf16_t* __restrict__ P, int ldP, const bf16_t* __restrict__ V, int ldV,
+                const float* __restrict__ qa, int ld_qa, const float* __restrict__ w_a,
+                const float* __restrict__ c_a, const float* __restrict__ inv_norm, float* __restrict__ p_out,
+                bf16_t* __restrict__ pooled_t, float* __restrict__ pooled_f32, int ld_pool, int R, int A, int Dv) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_s = smem;
+    float* w_s = s_s + ((R + 3) & ~3);
+    float* red = w_s + ((R + 3) & ~3);
+    __shared__ float red2[ATT_WAVES];
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const bf16_t* Pb = P + (size_t)b * R * ldP;
+    const bf16_t* Vb = V + (size_t)b * R * ldV;
+    const int nva = A >> 3, nv = Dv >> 3;
+    const int G = ATT_THREADS / nv, grp = tid / nv, cv = tid % nv;
+
+    // ---- phase 1: scores ----------------------------------------------------------------
+    // qa and w_a go through LDS (coalesced), then this lane's slices stay in registers.  Every
+    // load below is unconditional (indices clamped, contributions of the clamped lanes are
+    // multiplied by a zero weight) so that the loads of the next row stay in flight under the
+    // arithmetic of the current one.
+    const float kk = 2.8853900817779268f;                 // 2 * log2(e)
+    for (int a = tid; a < A; a += ATT_THREADS) { red[a] = qa[(size_t)b * ld_qa + a] * kk; red[A + a] = 2.f * w_a[a]; }
+    __syncthreads();
+    float qk[NVA][8], w2[NVA][8];
+    float wsum = 0.f;
+    int voff[NVA];
+#pragma unroll
+    for (int i = 0; i < NVA; ++i) {
+        const int v = lane + 64 * i;
+        const int vc = min(v, nva - 1);
+        const float live = v < nva ? 1.f : 0.f;
+        voff[i] = vc * 8;
+        const f32x4 q0 = *reinterpret_cast<const f32x4*>(red + vc * 8), q1 = *reinterpret_cast<const f32x4*>(red + vc * 8 + 4);
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(red + A + vc * 8), g1 = *reinterpret_cast<const f32x4*>(red + A + vc * 8 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            qk[i][e] = q0[e]; qk[i][4 + e] = q1[e];
+            w2[i][e] = g0[e] * live; w2[i][4 + e] = g1[e] * live;
+            wsum += 0.5f * (w2[i][e] + w2[i][4 + e]);
+        }
+    }
+    wsum = wave_sum(wsum) + c_a[0];
+    __syncthreads();                                       // red is reused by the pooling phase
+    u32x4_t cur[NVA], nxt[NVA];
+    {
+        const bf16_t* row = Pb + (size_t)min(wv, R - 1) * ldP;
+#pragma unroll
+        for (int i = 0; i < NVA; ++i) cur[i] = __builtin_bit_cast(u32x4_t, ld_stream(row + voff[i]));
+    }
+    for (int r = wv; r < R; r += ATT_WAVES) {
+        const bf16_t* rown = Pb + (size_t)min(r + ATT_WAVES, R - 1) * ldP;
+#pragma unroll
+        for (int i = 0; i < NVA; ++i) nxt[i] = __builtin_bit_cast(u32x4_t, ld_stream(rown + voff[i]));
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < NVA; ++i)
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                const float y0 = fmaf(bf16_lo(cur[i][h]), kk, qk[i][2 * h]);
+                const float y1 = fmaf(bf16_hi(cur[i][h]), kk, qk[i][2 * h + 1]);
+                acc = fmaf(w2[i][2 * h], __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(y0) + 1.0f), acc);
+                acc = fmaf(w2[i][2 * h + 1], __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(y1) + 1.0f), acc);
+            }
+        acc = wave_sum(acc);
+        if (lane == 0) s_s[r] = wsum - acc;
+#pragma unroll
+        for (int i = 0; i < NVA; ++i) cur[i] = nxt[i];
+    }
+    __syncthreads();
+
+    // ---- phase 2: softmax over regions ---------------------------------------------
+    float mx = -INFINITY;
+    for (int i = tid; i < R; i += ATT_THREADS) mx = fmaxf(mx, s_s[i]);
+    mx = block_max(mx, red2);
+    float se = 0.f;
+    for (int i = tid; i < R; i += ATT_THREADS) se += expf(s_s[i] - mx);
+    se = block_sum(se, red2);
+    const float inv_se = 1.0f / se;
+    for (int i = tid; i < R; i += ATT_THREADS) {
+        const float p = expf(s_s[i] - mx) * inv_se;
+        p_out[(size_t)b * R + i] = p;
+        w_s[i] = p * inv_norm[(size_t)b * R + i];
+    }
+    __syncthreads();
+
+    // ---- phase 3: pooling, 8 rows in flight per thread -------------------------------------
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (grp < G) {
+        const bf16_t* col = Vb + cv * 8;
+        int rr = grp;
+        for (; rr + 7 * G < R; rr += 8 * G) {
+            u32x4_t x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = __builtin_bit_cast(u32x4_t, ld_stream(col + (size_t)(rr + u * G) * ldV));
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float w = w_s[rr + u * G];
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    acc[2 * h] = fmaf(w, bf16_lo(x[u][h]), acc[2 * h]);
+                    acc[2 * h + 1] = fmaf(w, bf16_hi(x[u][h]), acc[2 * h + 1]);
+                }
+            }
+        }
+        for (; rr < R; rr += G) {
+            const u32x4_t x = __builtin_bit_cast(u32x4_t, ld_stream(col + (size_t)rr * ldV));
+            const float w = w_s[rr];
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                acc[2 * h] = fmaf(w, bf16_lo(x[h]), acc[2 * h]);
+                acc[2 * h + 1] = fmaf(w, bf16_hi(x[h]), acc[2 * h + 1]);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[(size_t)(grp * nv + cv) * 8 + e] = acc[e];
+    }
+    __syncthreads();
+    for (int d = tid; d < Dv; d += ATT_THREADS) {
+        float s = 0.f;
+        for (int g = 0; g < G; ++g) s += red[(size_t)g * Dv + d];
+        if (pooled_f32) pooled_f32[(size_t)b * ld_pool + d] = s;
+        if (pooled_t) pooled_t[(size_t)b * ld_pool + d] = f32_to_bf16(s);
+    }
+}
+
+// Backward, bf16, pipelined.  Same results layout as k_attn_bwd.  NVD = ceil(Dv / 512).
+// Phase C uses r = 1/(exp2(k (P+qa)) + 1):  t = 1 - 2r,  1 - t^2 = 4 r (1 - r).
+template <int NVD>
+__global__ void __launch_bounds__(ATT_THREADS)
+k_attn_bwd_pipe(const bf16_t* __restrict__ P, int ldP, const bf16_t* __restrict__ V, int ldV,
+                const float* __restrict__ qa, int ld_qa, const float* __restrict__ w_a,
+                const float* __restrict__ inv_norm, const float* __restrict__ p_in,
+                const float* __restrict__ d_pooled, int ld_dpool, bf16_t* __restrict__ dP, int ld_dP,
+                float* __restrict__ dqa_f32, bf16_t* __restrict__ dqa_t, int ld_dqa, float* __restrict__ dwa_part,
+                float* __restrict__ dc_part, int R, int A, int Dv) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* dpool_s = smem;
+    float* ds_s = dpool_s + Dv;
+    float* wn_s = ds_s + ((R + 3) & ~3);
+    float* red = wn_s + ((R + 3) & ~3);
+    __shared__ float red2[ATT_WAVES];
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const bf16_t* Pb = P + (size_t)b * R * ldP;
+    const bf16_t* Vb = V + (size_t)b * R * ldV;
+    bf16_t* dPb = dP + (size_t)b * R * ld_dP;
+    const int nv = Dv >> 3, nva = A >> 3;
+
+    for (int d = tid; d < Dv; d += ATT_THREADS) dpool_s[d] = d_pooled[(size_t)b * ld_dpool + d];
+    for (int r = tid; r < R; r += ATT_THREADS) wn_s[r] = inv_norm[(size_t)b * R + r];
+    __syncthreads();
+
+    // ---- phase A: dp_r = inv_norm_r * (d_pooled . V_r), one wave per row, next row in flight ----
+    {
+        float dv[NVD][8];
+        int voff[NVD];
+#pragma unroll
+        for (int i = 0; i < NVD; ++i) {
+            const int v = lane + 64 * i, vc = min(v, nv - 1);
+            const float live = v < nv ? 1.f : 0.f;
+            voff[i] = vc * 8;
+            const f32x4 d0 = *reinterpret_cast<const f32x4*>(dpool_s + vc * 8), d1 = *reinterpret_cast<const f32x4*>(dpool_s + vc * 8 + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { dv[i][e] = d0[e] * live; dv[i][4 + e] = d1[e] * live; }
+        }
+        u32x4_t cur[NVD], nxt[NVD];
+        {
+            const bf16_t* row = Vb + (size_t)min(wv, R - 1) * ldV;
+#pragma unroll
+            for (int i = 0; i < NVD; ++i) cur[i] = __builtin_bit_cast(u32x4_t, ld_stream(row + voff[i]));
+        }
+        for (int r = wv; r < R; r += ATT_WAVES) {
+            const bf16_t* rown = Vb + (size_t)min(r + ATT_WAVES, R - 1) * ldV;
+#pragma unroll
+            for (int i = 0; i < NVD; ++i) nxt[i] = __builtin_bit_cast(u32x4_t, ld_stream(rown + voff[i]));
+            float acc = 0.f;
+#pragma unroll
+            for (int i = 0; i < NVD; ++i)
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    acc = fmaf(dv[i][2 * h], bf16_lo(cur[i][h]), acc);
+                    acc = fmaf(dv[i][2 * h + 1], bf16_hi(cur[i][h]), acc);
+                }
+            acc = wave_sum(acc);
+            if (lane == 0) ds_s[r] = acc * wn_s[r];
+#pragma unroll
+            for (int i = 0; i < NVD; ++i) cur[i] = nxt[i];
+        }
+    }
+    __syncthreads();
+
+    // ---- phase B: softmax backward -----------------------------------------------------
+    float dot = 0.f;
+    for (int r = tid; r < R; r += ATT_THREADS) dot += p_in[(size_t)b * R + r] * ds_s[r];
+    dot = block_sum(dot, red2);
+    float dsum = 0.f;
+    for (int r = tid; r < R; r += ATT_THREADS) {
+        const float ds = p_in[(size_t)b * R + r] * (ds_s[r] - dot);
+        ds_s[r] = ds;
+        dsum += ds;
+    }
+    dsum = block_sum(dsum, red2);
+    if (tid == 0 && dc_part) dc_part[b] = dsum;
+    __syncthreads();
+
+    // ---- phase C: stream P, write dP, accumulate dqa / dwa; 4 rows in flight per thread ------
+    const int G = ATT_THREADS / nva, grp = tid / nva, cv = tid % nva;
+    const bool active = grp < G;
+    const float kk = 2.8853900817779268f;
+    float aq[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ar[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float dssum = 0.f;
+    if (active) {
+        float qk[8], w4[8];
+        {
+            const f32x4 q0 = *reinterpret_cast<const f32x4*>(qa + (size_t)b * ld_qa + cv * 8);
+            const f32x4 q1 = *reinterpret_cast<const f32x4*>(qa + (size_t)b * ld_qa + cv * 8 + 4);
+            const f32x4 g0 = *reinterpret_cast<const f32x4*>(w_a + cv * 8), g1 = *reinterpret_cast<const f32x4*>(w_a + cv * 8 + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { qk[e] = q0[e] * kk; qk[4 + e] = q1[e] * kk; w4[e] = 4.f * g0[e]; w4[4 + e] = 4.f * g1[e]; }
+        }
+        const bf16_t* colP = Pb + cv * 8;
+        bf16_t* colD = dPb + cv * 8;
+        auto body = [&](const u32x4_t& x, int r) {
+            const float ds = ds_s[r], wn = wn_s[r];
+            dssum += ds;
+            float o[8];
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+#pragma unroll
+                for (int z = 0; z < 2; ++z) {
+                    const int e = 2 * h + z;
+                    const float y = fmaf(z ? bf16_hi(x[h]) : bf16_lo(x[h]), kk, qk[e]);
+                    const float rr = __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(y) + 1.0f);
+                    const float g = ds * w4[e] * (rr - rr * rr);
+                    aq[e] += g;
+                    ar[e] = fmaf(ds, rr, ar[e]);
+                    o[e] = g * wn;
+                }
+            }
+            u16x8 ov;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ov[e] = f32_to_bf16(o[e]);
+            __builtin_nontemporal_store(ov, reinterpret_cast<u16x8*>(colD + (size_t)r * ld_dP));
+        };
+        int r = grp;
+        for (; r + 3 * G < R; r += 4 * G) {
+            u32x4_t x[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) x[u] = __builtin_bit_cast(u32x4_t, ld_stream(colP + (size_t)(r + u * G) * ldP));
+#pragma unroll
+            for (int u = 0; u < 4; ++u) body(x[u], r + u * G);
+        }
+        for (; r < R; r += G) {
+            const u32x4_t x = __builtin_bit_cast(u32x4_t, ld_stream(colP + (size_t)r * ldP));
+            body(x, r);
+        }
+    }
+    // fixed-order reduction over the G row groups: dqa, then dwa = sum ds - 2 sum ds r
+    if (active) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[(size_t)(grp * nva + cv) * 8 + e] = aq[e];
+    }
+    __syncthreads();
+    for (int a = tid; a < A; a += ATT_THREADS) {
+        float s = 0.f;
+        for (int g = 0; g < G; ++g) s += red[(size_t)g * A + a];
+        dqa_f32[(size_t)b * ld_dqa + a] = s;
+        if (dqa_t) dqa_t[(size_t)b * ld_dqa + a] = f32_to_bf16(s);
+    }
+    __syncthreads();
+    if (active) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[(size_t)(grp * nva + cv) * 8 + e] = dssum - 2.f * ar[e];
+    }
+    __syncthreads();
+    for (int a = tid; a < A; a += ATT_THREADS) {
+        float s = 0.f;
+        for (int g = 0; g < G; ++g) s += red[(size_t)g * A + a];
+        dwa_part[(size_t)b * ld_dqa + a] = s;
+    }
+}
+
 extern "C" {
 
 size_t vqa_attn_lds_bytes(int R, int A, int Dv) {
@@ -309,6 +630,20 @@ int vqa_attn_fwd(const void* P, int ldP, const void* V, int ldV, const float* qa
     VQA_REQUIRE(ld_qa >= A && ld_pool >= Dv, "vqa_attn_fwd: ld_qa / ld_pool too small");
     if (B == 0) return 0;
     const size_t lds = ((size_t)2 * A + R + ((R + 3) & ~3) + (size_t)ATT_THREADS * 8) * sizeof(float);
+    const int nva_l = (A / 8 + 63) / 64;
+    if (dtype == VQA_BF16 && Dv / 8 <= ATT_THREADS && nva_l <= 4) {
+        const size_t lds_p = ((size_t)2 * ((R + 3) & ~3) + (size_t)ATT_THREADS * 8) * sizeof(float);
+#define ATT_FWD_PIPE(NVA)                                                                                          \
+  {                                                                                                                \
+    if (lds_p > 48 * 1024)                                                                                         \
+        VQA_REQUIRE(hipFuncSetAttribute((const void*)k_attn_fwd_pipe<NVA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p) == hipSuccess, "vqa_attn_fwd: cannot reserve LDS"); \
+    k_attn_fwd_pipe<NVA><<<B, ATT_THREADS, lds_p, stream>>>((const bf16_t*)P, ldP, (const bf16_t*)V, ldV, qa, \
+        ld_qa, w_a, c_a, inv_norm, p_out, (bf16_t*)pooled_t, pooled_f32, ld_pool, R, A, Dv);               \
+  }
+        if (nva_l == 1) ATT_FWD_PIPE(1) else if (nva_l == 2) ATT_FWD_PIPE(2) else if (nva_l == 3) ATT_FWD_PIPE(3) else ATT_FWD_PIPE(4)
+#undef ATT_FWD_PIPE
+        return vqa_check_launch("vqa_attn_fwd");
+    }
     if (dtype == VQA_F32) {
         VQA_REQUIRE(hipFuncSetAttribute((const void*)k_attn_fwd<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess, "vqa_attn_fwd: cannot reserve LDS");
         k_attn_fwd<float><<<B, ATT_THREADS, lds, stream>>>((const float*)P, ldP, (const float*)V, ldV, qa, ld_qa, w_a, c_a,
@@ -331,6 +666,19 @@ int vqa_attn_bwd(const void* P, int ldP, const void* V, int ldV, const float* qa
     if (B == 0) return 0;
     const size_t r4 = (size_t)((R + 3) & ~3);
     const size_t lds = ((size_t)Dv + 2 * r4 + (size_t)ATT_THREADS * 8) * sizeof(float);
+    const int nvd_l = (Dv / 8 + 63) / 64;
+    if (dtype == VQA_BF16 && A / 8 <= ATT_THREADS && nvd_l <= 4 && ((ld_qa & 3) == 0) && ((((uintptr_t)qa | (uintptr_t)w_a) & 15) == 0)) {
+#define ATT_BWD_PIPE(NVD)                                                                                          \
+  {                                                                                                                \
+    if (lds > 48 * 1024)                                                                                           \
+        VQA_REQUIRE(hipFuncSetAttribute((const void*)k_attn_bwd_pipe<NVD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess, "vqa_attn_bwd: cannot reserve LDS"); \
+    k_attn_bwd_pipe<NVD><<<B, ATT_THREADS, lds, stream>>>((const bf16_t*)P, ldP, (const bf16_t*)V, ldV, qa, ld_qa, w_a,  \
+        inv_norm, p_in, d_pooled, ld_dpool, (bf16_t*)dP, ld_dP, dqa_f32, (bf16_t*)dqa_t, ld_dqa, dwa_part, dc_part, R, A, Dv); \
+  }
+        if (nvd_l == 1) ATT_BWD_PIPE(1) else if (nvd_l == 2) ATT_BWD_PIPE(2) else if (nvd_l == 3) ATT_BWD_PIPE(3) else ATT_BWD_PIPE(4)
+#undef ATT_BWD_PIPE
+        return vqa_check_launch("vqa_attn_bwd");
+    }
     if (dtype == VQA_F32) {
         VQA_REQUIRE(hipFuncSetAttribute((const void*)k_attn_bwd<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess, "vqa_attn_bwd: cannot reserve LDS");
         k_attn_bwd<float><<<B, ATT_THREADS, lds, stream>>>((const float*)P, ldP, (const float*)V, ldV, qa, ld_qa, w_a, inv_norm,
