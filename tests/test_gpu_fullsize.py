@@ -1,0 +1,125 @@
+"""Full-size (BASELINE config) GPU checks through size-independent properties, plus oracle parity on
+sub-batches at the real model widths (Dv=2048, A=F=1200, Hq=2400, E=620, Hf=256, C=3000, L=14)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import vqa_ref
+
+pytestmark = pytest.mark.gpu
+
+FULL = dict(vq=10000, C=3000, E=620, Hq=2400, Dv=2048, A=1200, F=1200, Hf=256)
+
+
+def rel_err(got, ref):
+    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+    return float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+
+
+@pytest.fixture(scope='module')
+def full_model():
+    from vqa_amd.model import VQAAttnModel
+    p = vqa_ref.init_params(hops=1, seed=11, **FULL)
+    m = VQAAttnModel(['w'] * FULL['vq'], ['a'] * FULL['C'], None, dtype=torch.bfloat16, seed=5)
+    m.load_state_dict(p)
+    return m.to('cuda'), p
+
+
+def test_cfg2_rows_match_oracle_and_are_independent(full_model):
+    """B=256, R=196 (config 2).  Rows are independent in every kernel (what makes data-parallel sharding
+    exact): the logits of rows 0..3 inside the 256-batch equal the oracle's logits for those 4 rows alone,
+    and equal the module's own logits when the same rows are fed as a batch of 4."""
+    m, p = full_model
+    m.eval()
+    b = vqa_ref.synthetic_batch(256, 196, 2048, 14, FULL['vq'], FULL['C'], seed=42)
+    feats = b['feats'].to(torch.bfloat16)
+    logits = m(feats.cuda(), b['tokens'].cuda()).float().cpu()
+    assert logits.shape == (256, 3000) and bool(torch.isfinite(logits).all())
+    po = {k: v.to(torch.bfloat16).float() for k, v in p.items()}
+    ref = vqa_ref.forward(po, feats[:4].float(), b['tokens'][:4])
+    assert rel_err(logits[:4], ref) <= 1e-2
+    small = m(feats[:4].cuda(), b['tokens'][:4].cuda()).float().cpu()
+    assert rel_err(small, logits[:4]) <= 2e-3          # same rows, different tiling of the batch
+    # attention probabilities are a distribution over the 196 regions
+    ps = m._ctx[0]['p0']
+    ws4 = m._workspace(4, 196, 14, 0, torch.device('cuda', 0))['p0']
+    torch.cuda.synchronize()
+    assert torch.allclose(ws4.sum(1).cpu(), torch.ones(4), atol=1e-5)
+    # prediction: bit-exact first-max argmax of the logits the module produced
+    pred = m.predict().cpu().numpy()
+    lg = m._ctx[0]['logits'][:, :3000].float().cpu().numpy()
+    assert np.array_equal(pred, np.argmax(lg, axis=1))
+
+
+def test_cfg2_region_permutation_invariance(full_model):
+    """Attention pooling is a sum over regions: permuting the 196 regions of every sample leaves the logits
+    unchanged up to summation order."""
+    m, _ = full_model
+    m.eval()
+    b = vqa_ref.synthetic_batch(64, 196, 2048, 14, FULL['vq'], FULL['C'], seed=7)
+    feats = b['feats'].to(torch.bfloat16).cuda()
+    tok = b['tokens'].cuda()
+    a = m(feats, tok).float()
+    perm = torch.randperm(196, generator=torch.Generator().manual_seed(0)).cuda()
+    c = m(feats[:, perm].contiguous(), tok).float()
+    assert rel_err(c, a) <= 2e-3
+
+
+def test_cfg2_train_step_gradients_subbatch(full_model):
+    """fwd + CE + bwd at the real widths on a batch of 8 against the oracle's autograd (bf16 tolerance)."""
+    m, p = full_model
+    m.eval()
+    b = vqa_ref.synthetic_batch(8, 196, 2048, 14, FULL['vq'], FULL['C'], seed=3)
+    feats = b['feats'].to(torch.bfloat16)
+    po = {k: v.to(torch.bfloat16).float() for k, v in p.items()}
+    _, loss_ref, grads = vqa_ref.loss_and_grads(po, feats.float(), b['tokens'], b['answers'])
+    with torch.no_grad():
+        m._forward_impl(*m._prepare_inputs(feats.cuda(), b['tokens'].cuda(), None))
+        loss = m.loss_and_grad_logits(b['answers'].cuda())
+        m._backward_impl()
+    assert abs(float(loss) - float(loss_ref)) <= 1e-2 * float(loss_ref)
+    named = dict(m.named_parameters())
+    for k, g in grads.items():
+        if k.endswith('linear_a.bias'):
+            continue
+        got = m._g(k).view(named[k].shape)
+        assert rel_err(got, g) <= 3e-2, (k, rel_err(got, g))
+
+
+def test_cfg5_large_grid_two_hops_runs_and_matches_subbatch():
+    """Config 5 shape: 24x24 regions, 2 stacked hops, batch 512 per GPU; rows 0..1 against the oracle."""
+    from vqa_amd.model import VQAAttnModel
+    p = vqa_ref.init_params(hops=2, seed=12, **FULL)
+    m = VQAAttnModel(['w'] * FULL['vq'], ['a'] * FULL['C'], None, dtype=torch.bfloat16, hops=2, seed=5)
+    m.load_state_dict(p)
+    m = m.to('cuda').train()
+    g = torch.Generator(device='cuda').manual_seed(1)
+    B, R = 512, 576
+    feats = torch.randn((B, R, 2048), device='cuda', generator=g).clamp_min_(0).to(torch.bfloat16)
+    b = vqa_ref.synthetic_batch(B, 1, 8, 14, FULL['vq'], FULL['C'], seed=9)
+    loss0 = float(m.train_step(feats, b['tokens'].cuda(), b['answers'].cuda(), lr=1e-4))
+    for _ in range(3):
+        loss = float(m.train_step(feats, b['tokens'].cuda(), b['answers'].cuda(), lr=1e-4))
+    assert np.isfinite(loss0) and np.isfinite(loss) and loss < loss0      # same batch: loss falls
+    m.eval()
+    logits = m(feats, b['tokens'].cuda()).float().cpu()
+    po = {k: v.detach().float().cpu().to(torch.bfloat16).float() for k, v in m.state_dict().items()}
+    ref = vqa_ref.forward(po, feats[:2].float().cpu(), b['tokens'][:2], hops=2)
+    assert rel_err(logits[:2], ref) <= 1e-2
+
+
+def test_cfg4_caption_stream_full_width():
+    """Config 4: caption stream (16-token captions, 384-d caption vectors) at the real widths."""
+    from vqa_amd.model import VQAAttnModel
+    kw = dict(FULL)
+    p = vqa_ref.init_params(hops=1, seed=13, vc=5000, Ec=384, **kw)
+    m = VQAAttnModel(['w'] * FULL['vq'], ['a'] * FULL['C'], None, dtype=torch.bfloat16, caption_vocab=5000,
+                     caption_dim=384, seed=5)
+    m.load_state_dict(p)
+    m = m.to('cuda').eval()
+    b = vqa_ref.synthetic_batch(32, 196, 2048, 14, FULL['vq'], FULL['C'], seed=4, Tc=16, vc=5000)
+    feats = b['feats'].to(torch.bfloat16)
+    logits = m(feats.cuda(), b['tokens'].cuda(), b['captions'].cuda()).float().cpu()
+    po = {k: v.to(torch.bfloat16).float() for k, v in p.items()}
+    ref = vqa_ref.forward(po, feats[:4].float(), b['tokens'][:4], b['captions'][:4])
+    assert rel_err(logits[:4], ref) <= 1e-2

@@ -1,0 +1,20 @@
+"""Runs one GEMM shape a few times (for counter passes).  args: name"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from vqa_amd._lib import call, ptr
+which = sys.argv[1] if len(sys.argv) > 1 else 'k4'
+dt = torch.bfloat16
+if which == 'k4':
+    M, N, K, akm, bkm, sk = 50176, 1200, 2048, 1, 1, 1
+elif which == 'wgrad':
+    M, N, K, akm, bkm, sk = 1200, 2048, 50176, 0, 0, 3
+else:
+    M, N, K, akm, bkm, sk = 256, 9600, 2400, 1, 1, 3
+A = (torch.randn((M, K) if akm else (K, M), device='cuda') * 0.5).to(dt)
+Bm = (torch.randn((N, K) if bkm else (K, N), device='cuda') * 0.5).to(dt)
+slab = torch.empty(sk * M * N, device='cuda', dtype=torch.float32)
+for _ in range(4):
+    call('vqa_gemm_slabs', ptr(A), K if akm else M, akm, ptr(Bm), K if bkm else N, bkm, ptr(slab), M * N, N, M, N, K, sk, 1, 0)
+torch.cuda.synchronize()
+print('ok')

@@ -78,8 +78,18 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
+_stream_handle = None
+
+
 def stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    """HIP stream the kernels are enqueued on: torch's current stream, looked up once per
+    public entry of the module (bind_stream) rather than once per kernel."""
+    return _stream_handle if _stream_handle is not None else torch.cuda.current_stream().cuda_stream
+
+
+def bind_stream() -> None:
+    global _stream_handle
+    _stream_handle = torch.cuda.current_stream().cuda_stream
 
 
 def call(name: str, *args):

@@ -400,6 +400,7 @@ class VQAAttnModel(nn.Module):
         """Embedding gather + LSTM + last-valid-step selection -> q (B, Hq) fp32."""
         B, L = tokens.shape
         dev = tokens.device
+        _lib.bind_stream()
         self._refresh_frozen(dev)
         if ws is None:
             ws = self._workspace(B, 1, L, 0, dev)
@@ -425,6 +426,7 @@ class VQAAttnModel(nn.Module):
         L = tokens.shape[1]
         dev = feats.device
         Tc = captions.shape[1] if captions is not None else 0
+        _lib.bind_stream()
         self._materialize(dev)
         self._refresh_shadow()
         ws = self._workspace(B, R, L, Tc, dev)
@@ -471,6 +473,7 @@ class VQAAttnModel(nn.Module):
         ws, feats, B, R, L, seeds, p = self._ctx
         C, Cp = self.num_classes, _pad8(self.num_classes)
         d = dlogits.to(torch.float32).contiguous()
+        _lib.bind_stream()
         call('vqa_cast_pad', ptr(d), C, ptr(ws['dlogits']), Cp, B, C, self.dt)
         self._backward_impl()
 
@@ -478,6 +481,7 @@ class VQAAttnModel(nn.Module):
         """Gradients of every trainable parameter from ws['dlogits'] into the flat gradient buffer."""
         ws, feats, B, R, L, seeds, p = self._ctx
         H, A, Dv, F, Hf, Ec, C, Cp, dt = self.Hq, self.A, self.Dv, self.F, self.Hf, self.Ec, self.num_classes, _pad8(self.num_classes), self.dt
+        _lib.bind_stream()
         g = self._g
         # classifier
         self._wgrad(ws['dlogits'], Cp, ws['h1d'], Hf, 'linear_classif2.weight', C, Hf, B)
@@ -536,6 +540,7 @@ class VQAAttnModel(nn.Module):
         ws, feats, B, R, L, seeds, p = self._ctx
         C, Cp = self.num_classes, _pad8(self.num_classes)
         ans = answers.long().contiguous()
+        _lib.bind_stream()
         call('vqa_softmax_ce', ptr(ws['logits']), Cp, ptr(ans), ptr(ws['loss_rows']), ptr(ws['dlogits']), Cp, B, C,
              1.0 / B, self.dt)
         call('vqa_sum_scale', ptr(ws['loss_rows']), ptr(ws['loss']), B, 1.0 / B)
@@ -546,6 +551,7 @@ class VQAAttnModel(nn.Module):
         accumulates per-question-type count / right counters on the device."""
         ws, feats, B, R, L, seeds, p = self._ctx
         C, Cp = self.num_classes, _pad8(self.num_classes)
+        _lib.bind_stream()
         call('vqa_argmax_accuracy', ptr(ws['logits']), Cp, B, C, ptr(answers), ptr(type_ids), n_types, ptr(ws['pred']),
              ptr(counters))
         return ws['pred']
@@ -556,6 +562,7 @@ class VQAAttnModel(nn.Module):
             self._exp_avg = torch.zeros_like(self._flat)
             self._exp_avg_sq = torch.zeros_like(self._flat)
         self.step_count += 1
+        _lib.bind_stream()
         call('vqa_adam_step', ptr(self._flat), ptr(self._flat_grad), ptr(self._exp_avg), ptr(self._exp_avg_sq),
              ptr(self._shadow), self._flat.numel(), lr, betas[0], betas[1], eps, self.step_count, grad_scale)
         self._shadow_fresh = self.dt == _lib.BF16
