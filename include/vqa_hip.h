@@ -93,7 +93,7 @@ int vqa_attn_bwd(const void* P, int ldP, const void* V, int ldV, const float* qa
  * nn.Linear weight), 0 when stored [K][M] / [K][N].  engine: 0 = MFMA for bf16 (fp32 always
  * runs the VALU kernel), 1 = force the VALU kernel (cross-check).
  *                   nn.Linear forward / backward: model.py:44, 55-58, 63, 68, 74, 77 */
-int vqa_gemm_splitk_hint(int M, int N, int K);
+int vqa_gemm_splitk_hint(int M, int N, int K, int a_kmajor, int b_kmajor);
 /* fp32 partial sums: slabs[s][m][n], s < splitk (consumers sum the slabs) */
 int vqa_gemm_slabs(const void* A, int lda, int a_kmajor, const void* B, int ldb, int b_kmajor, float* slabs,
                    size_t slab_stride, int ld_slab, int M, int N, int K, int splitk, int dtype, int engine,

@@ -30,7 +30,7 @@ def test_version_and_argument_errors_without_gpu():
     # argument validation happens before any HIP call
     rc = lib.vqa_inv_norm(None, None, 4, 12, 12, 0, None)
     assert rc == -22 and b'vqa_inv_norm' in lib.vqa_last_error_string()
-    assert lib.vqa_gemm_splitk_hint(256, 1200, 2048) >= 1
+    assert lib.vqa_gemm_splitk_hint(256, 1200, 2048, 1, 1) >= 1
     assert lib.vqa_attn_lds_bytes(196, 1200, 2048) <= 160 * 1024
 
 

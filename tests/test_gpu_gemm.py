@@ -1,0 +1,83 @@
+"""GEMM kernels through the C ABI: every MFMA tile configuration (64x64, 128x128, 256x128 ring) and operand
+layout against fp64 torch on ragged shapes (M, N not multiples of the tile, K tails, split-K, empty splits),
+plus the fused epilogue (row scale, bias, tanh, bf16 / fp32 output)."""
+import pytest
+import torch
+
+from vqa_amd._lib import call, ptr, BF16, F32
+
+pytestmark = pytest.mark.gpu
+
+
+def make(M, N, K, akm, bkm, dtype, seed):
+    g = torch.Generator(device='cuda').manual_seed(seed)
+    pad8 = lambda n: (n + 7) // 8 * 8
+    # logical operands
+    A = torch.randn(M, K, device='cuda', generator=g)
+    B = torch.randn(N, K, device='cuda', generator=g)
+    A = A.to(dtype).float()
+    B = B.to(dtype).float()
+    def store(X, kmajor):          # (rows, K) logical -> storage with a padded, zero-filled leading dimension
+        if kmajor:
+            ld = pad8(X.shape[1])
+            buf = torch.zeros(X.shape[0], ld, device='cuda', dtype=dtype)
+            buf[:, :X.shape[1]] = X.to(dtype)
+        else:
+            ld = pad8(X.shape[0])
+            buf = torch.zeros(X.shape[1], ld, device='cuda', dtype=dtype)
+            buf[:, :X.shape[0]] = X.t().to(dtype)
+        return buf, ld
+    As, lda = store(A, akm)
+    Bs, ldb = store(B, bkm)
+    ref = A.double() @ B.double().t()
+    return As, lda, Bs, ldb, ref
+
+
+SHAPES = [(37, 50, 72), (130, 70, 200), (300, 129, 64), (257, 384, 1000), (512, 136, 40), (64, 64, 8), (1, 9, 640)]
+
+
+@pytest.mark.parametrize('engine', [2, 3, 4, 1])
+@pytest.mark.parametrize('akm,bkm', [(1, 1), (1, 0), (0, 1), (0, 0)])
+def test_slab_gemm_all_layouts(engine, akm, bkm):
+    for si, (M, N, K) in enumerate(SHAPES):
+        for sk in (1, 3):
+            As, lda, Bs, ldb, ref = make(M, N, K, akm, bkm, torch.bfloat16, 10 * si + sk)
+            slab = torch.full((sk, M, N), float('nan'), device='cuda')
+            call('vqa_gemm_slabs', ptr(As), lda, akm, ptr(Bs), ldb, bkm, ptr(slab), M * N, N, M, N, K, sk, BF16, engine)
+            torch.cuda.synchronize()
+            got = slab.double().sum(0)
+            err = float((got - ref).abs().max() / ref.abs().max())
+            assert err <= 2e-5, (engine, akm, bkm, M, N, K, sk, err)
+
+
+@pytest.mark.parametrize('engine', [2, 3, 4])
+@pytest.mark.parametrize('out_dtype', [torch.bfloat16, torch.float32])
+def test_fused_epilogue(engine, out_dtype):
+    for si, (M, N, K) in enumerate([(300, 136, 256), (515, 1200, 192), (96, 8, 72)]):
+        As, lda, Bs, ldb, ref = make(M, N, K, 1, 1, torch.bfloat16, 77 + si)
+        g = torch.Generator(device='cuda').manual_seed(si)
+        bias = torch.randn(N, device='cuda', generator=g)
+        rs = torch.rand(M, device='cuda', generator=g) * 0.2
+        ldc = (N + 7) // 8 * 8
+        for act in (0, 1):
+            C = torch.zeros(M, ldc, device='cuda', dtype=out_dtype)
+            call('vqa_gemm_fused', ptr(As), lda, 1, ptr(Bs), ldb, 1, ptr(C), ldc, M, N, K, ptr(bias), ptr(rs), act,
+                 BF16 if out_dtype == torch.bfloat16 else F32, BF16, engine)
+            torch.cuda.synchronize()
+            want = ref * rs.double()[:, None] + bias.double()[None, :]
+            if act:
+                want = torch.tanh(want)
+            tol = 1e-2 if out_dtype == torch.bfloat16 else 3e-5
+            err = float((C[:, :N].double() - want).abs().max() / want.abs().max())
+            assert err <= tol, (engine, out_dtype, M, N, K, act, err)
+            assert float(C[:, N:].abs().max() if ldc > N else 0.0) == 0.0      # padding untouched
+
+
+def test_fp32_gemm():
+    for akm, bkm in ((1, 1), (1, 0), (0, 0)):
+        As, lda, Bs, ldb, ref = make(77, 45, 131, akm, bkm, torch.float32, 5)
+        slab = torch.zeros(2, 77, 45, device='cuda')
+        call('vqa_gemm_slabs', ptr(As), lda, akm, ptr(Bs), ldb, bkm, ptr(slab), 77 * 45, 45, 77, 45, 131, 2, F32, 0)
+        torch.cuda.synchronize()
+        err = float((slab.double().sum(0) - ref).abs().max() / ref.abs().max())
+        assert err <= 1e-6

@@ -13,8 +13,9 @@ else:
     M, N, K, akm, bkm, sk = 256, 9600, 2400, 1, 1, 3
 A = (torch.randn((M, K) if akm else (K, M), device='cuda') * 0.5).to(dt)
 Bm = (torch.randn((N, K) if bkm else (K, N), device='cuda') * 0.5).to(dt)
+eng = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 slab = torch.empty(sk * M * N, device='cuda', dtype=torch.float32)
 for _ in range(4):
-    call('vqa_gemm_slabs', ptr(A), K if akm else M, akm, ptr(Bm), K if bkm else N, bkm, ptr(slab), M * N, N, M, N, K, sk, 1, 0)
+    call('vqa_gemm_slabs', ptr(A), K if akm else M, akm, ptr(Bm), K if bkm else N, bkm, ptr(slab), M * N, N, M, N, K, sk, 1, eng)
 torch.cuda.synchronize()
 print('ok')

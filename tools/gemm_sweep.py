@@ -22,13 +22,11 @@ def run(name, M, N, K, akm, bkm, variants):
     slab = torch.empty(max(v[1] for v in variants) * M * N, device='cuda', dtype=torch.float32)
     for eng, sk in variants:
         us = timeit(lambda: call('vqa_gemm_slabs', ptr(A), lda, int(akm), ptr(Bm), ldb, int(bkm), ptr(slab), M * N, N, M, N, K, sk, 1, eng))
-        print(f'{name:12s} M={M:6d} N={N:5d} K={K:6d} tile={"64" if eng == 2 else "128"} splitk={sk:2d}: {us:8.1f} us  {2.0 * M * N * K / us / 1e6:7.1f} TF')
+        print(f'{name:12s} M={M:6d} N={N:5d} K={K:6d} tile={ {2: "64", 3: "128", 4: "256x128"}[eng] } splitk={sk:2d}: {us:8.1f} us  {2.0 * M * N * K / us / 1e6:7.1f} TF')
 
 if __name__ == '__main__':
-    run('K4 fwd NT', 50176, 1200, 2048, True, True, [(3, 1), (2, 1)])
-    run('wgrad TN', 1200, 2048, 50176, False, False, [(3, 1), (3, 2), (3, 3), (3, 4), (3, 6), (2, 1), (2, 2)])
-    run('lstm NT', 256, 9600, 2400, True, True, [(3, 1), (3, 2), (3, 3), (3, 4), (2, 1), (2, 2)])
-    run('head NT', 256, 1200, 2048, True, True, [(2, 1), (2, 4), (2, 7), (2, 8), (3, 4), (3, 8)])
-    run('head dgrad', 256, 2048, 1200, True, False, [(2, 1), (2, 4), (3, 4)])
-    run('head wgrad', 1200, 2048, 256, False, False, [(3, 1), (2, 1)])
-    run('xg NT', 3584, 9600, 640, True, True, [(3, 1), (2, 1)])
+    run('K4 fwd NT', 50176, 1200, 2048, True, True, [(3, 1), (4, 1)])
+    run('wgrad TN', 1200, 2048, 50176, False, False, [(3, 3), (4, 1), (4, 2), (4, 3), (4, 6)])
+    run('lstm NT', 256, 9600, 2400, True, True, [(3, 3), (4, 1), (4, 2), (4, 3)])
+    run('xg NT', 3584, 9600, 640, True, True, [(3, 1), (4, 1)])
+    run('cfg5 K4', 512 * 576, 1200, 2048, True, True, [(3, 1), (4, 1)])

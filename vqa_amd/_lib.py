@@ -29,7 +29,7 @@ _SIGNATURES = {
     'vqa_attn_lds_bytes': [_i, _i, _i],
     'vqa_attn_fwd': [_p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     'vqa_attn_bwd': [_p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _i, _p, _i, _p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _p],
-    'vqa_gemm_splitk_hint': [_i, _i, _i],
+    'vqa_gemm_splitk_hint': [_i, _i, _i, _i, _i],
     'vqa_gemm_slabs': [_p, _i, _i, _p, _i, _i, _p, _z, _i, _i, _i, _i, _i, _i, _i, _p],
     'vqa_gemm_fused': [_p, _i, _i, _p, _i, _i, _p, _i, _i, _i, _i, _p, _p, _i, _i, _i, _i, _p],
     'vqa_epilogue': [_p, _i, _z, _i, _i, _p, _p, _p, _i, _i, _p, _i, _p, _i, _i, _u, _f, _p],

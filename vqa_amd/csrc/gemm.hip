@@ -62,7 +62,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 template <int ROWS, bool KMAJOR> struct Tile;
 template <int ROWS> struct Tile<ROWS, true> {
     static constexpr int BYTES = ROWS * 128;
-    static constexpr int NI = BYTES / 4096;                 // DMA instructions per wave
+    template <int NW> static constexpr int ni() { return BYTES / (NW * 1024); }   // DMA instructions per wave
     static __device__ __forceinline__ int swz(int row) { return row & 7; }
     static __device__ __forceinline__ int off(int row, int c) { return row * 128 + ((c ^ swz(row)) << 4); }
     // slot (instruction gi, lane) -> tile row and source chunk
@@ -75,9 +75,9 @@ template <int ROWS> struct Tile<ROWS, false> {
     static constexpr int RB = ROWS * 2;                     // bytes per k-row
     static constexpr int CPR = ROWS / 8;                    // chunks per k-row
     static constexpr int BYTES = 64 * RB;
-    static constexpr int NI = BYTES / 4096;
+    template <int NW> static constexpr int ni() { return BYTES / (NW * 1024); }
     static __device__ __forceinline__ int swz(int krow) {
-        return ROWS == 128 ? (((krow & 3) | (((krow >> 3) & 1) << 2)) << 1)
+        return ROWS >= 128 ? (((krow & 3) | (((krow >> 3) & 1) << 2)) << 1)
                            : ((((krow >> 1) & 1) | (((krow >> 3) & 1) << 1)) << 1);
     }
     static __device__ __forceinline__ int off(int krow, int c) { return krow * RB + ((c ^ swz(krow)) << 4); }
@@ -90,13 +90,14 @@ template <int ROWS> struct Tile<ROWS, false> {
 
 // Source pointers of this lane's DMA slots for the tile at k = 0 (row / column indices past
 // the operand's extent are clamped: they only feed output rows / columns that are never stored).
-template <int ROWS, bool KMAJOR>
+template <int ROWS, bool KMAJOR, int NW = 4>
 __device__ __forceinline__ void dma_setup(const bf16_t* __restrict__ X, int ld, int row0, int nrows, int wave, int lane,
-                                          const bf16_t* (&src)[Tile<ROWS, KMAJOR>::NI]) {
+                                          const bf16_t* (&src)[Tile<ROWS, KMAJOR>::template ni<NW>()]) {
+    constexpr int NI = Tile<ROWS, KMAJOR>::template ni<NW>();
 #pragma unroll
-    for (int i = 0; i < Tile<ROWS, KMAJOR>::NI; ++i) {
+    for (int i = 0; i < NI; ++i) {
         int r, c;
-        Tile<ROWS, KMAJOR>::slot(wave * Tile<ROWS, KMAJOR>::NI + i, lane, r, c);
+        Tile<ROWS, KMAJOR>::slot(wave * NI + i, lane, r, c);
         if (KMAJOR) {
             const int row = min(row0 + r, nrows - 1);
             src[i] = X + (size_t)row * ld + c * 8;
@@ -107,23 +108,24 @@ __device__ __forceinline__ void dma_setup(const bf16_t* __restrict__ X, int ld, 
     }
 }
 
-template <int ROWS, bool KMAJOR>
-__device__ __forceinline__ void dma_issue(const bf16_t* const (&src)[Tile<ROWS, KMAJOR>::NI], size_t koff, char* lds, int wave) {
+template <int ROWS, bool KMAJOR, int NW = 4>
+__device__ __forceinline__ void dma_issue(const bf16_t* const (&src)[Tile<ROWS, KMAJOR>::template ni<NW>()], size_t koff, char* lds, int wave) {
     typedef __attribute__((address_space(1))) const void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
+    constexpr int NI = Tile<ROWS, KMAJOR>::template ni<NW>();
 #pragma unroll
-    for (int i = 0; i < Tile<ROWS, KMAJOR>::NI; ++i)
-        __builtin_amdgcn_global_load_lds((gptr_t)(src[i] + koff), (lptr_t)(lds + (wave * Tile<ROWS, KMAJOR>::NI + i) * 1024), 16, 0, 0);
+    for (int i = 0; i < NI; ++i)
+        __builtin_amdgcn_global_load_lds((gptr_t)(src[i] + koff), (lptr_t)(lds + (wave * NI + i) * 1024), 16, 0, 0);
 }
 
 // register path (partial K tiles): global -> registers with zero fill, then -> the same LDS image
-template <int ROWS, bool KMAJOR>
+template <int ROWS, bool KMAJOR, int NW = 4>
 __device__ __forceinline__ void tile_load(const bf16_t* __restrict__ X, int ld, int row0, int nrows, int k0, int kend,
-                                          u32x4 (&r)[ROWS / 32]) {
+                                          u32x4 (&r)[ROWS / (8 * NW)]) {
     const int tid = threadIdx.x;
 #pragma unroll
-    for (int i = 0; i < ROWS / 32; ++i) {
-        const int q = tid + 256 * i;
+    for (int i = 0; i < ROWS / (8 * NW); ++i) {
+        const int q = tid + NW * 64 * i;
         u32x4 v = {0u, 0u, 0u, 0u};
         if (KMAJOR) {
             const int row = row0 + (q >> 3), k = k0 + ((q & 7) << 3);
@@ -137,12 +139,12 @@ __device__ __forceinline__ void tile_load(const bf16_t* __restrict__ X, int ld, 
     }
 }
 
-template <int ROWS, bool KMAJOR>
-__device__ __forceinline__ void tile_store(char* lds, const u32x4 (&r)[ROWS / 32]) {
+template <int ROWS, bool KMAJOR, int NW = 4>
+__device__ __forceinline__ void tile_store(char* lds, const u32x4 (&r)[ROWS / (8 * NW)]) {
     const int tid = threadIdx.x;
 #pragma unroll
-    for (int i = 0; i < ROWS / 32; ++i) {
-        const int q = tid + 256 * i;
+    for (int i = 0; i < ROWS / (8 * NW); ++i) {
+        const int q = tid + NW * 64 * i;
         int off;
         if (KMAJOR) off = Tile<ROWS, true>::off(q >> 3, q & 7);
         else off = Tile<ROWS, false>::off(q / (ROWS / 8), q % (ROWS / 8));
@@ -171,10 +173,10 @@ __device__ __forceinline__ bf16x8_t frag_read(const char* lds, int r0, int kk, i
 
 // Accumulators -> global through LDS so that every store instruction writes whole 64..256-byte
 // row segments.  Each wave stages 32 rows of its (BM/2 x BN/2) tile at a time as fp32.
-template <int BM, int BN>
-__device__ __forceinline__ void epilogue_store(char* lds, f32x4 (&acc)[BM / 32][BN / 32], const Epi& epi, int split,
+template <int MT, int NT>
+__device__ __forceinline__ void epilogue_store(char* lds, f32x4 (&acc)[MT][NT], const Epi& epi, int split,
                                                int m_w, int n_w, int M, int N, int wave, int lane) {
-    constexpr int MT = BM / 32, NT = BN / 32, WN = BN / 2, LDW = WN + 4;
+    constexpr int WN = NT * 16, LDW = WN + 4;
     float* wl = reinterpret_cast<float*>(lds) + wave * (32 * LDW);
     float bias[NT];
 #pragma unroll
@@ -276,8 +278,8 @@ k_gemm_bf16(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B,
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const bf16_t* sa[TA::NI];
-    const bf16_t* sb[TB::NI];
+    const bf16_t* sa[TA::template ni<4>()];
+    const bf16_t* sb[TB::template ni<4>()];
     dma_setup<BM, AKM>(A, lda, m0, M, wave, lane, sa);
     dma_setup<BN, BKM>(B, ldb, n0, N, wave, lane, sb);
     const size_t ka = AKM ? 1 : (size_t)lda, kb = BKM ? 1 : (size_t)ldb;   // elements per unit of k
@@ -337,7 +339,106 @@ k_gemm_bf16(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B,
         __syncthreads();
     }
 
-    epilogue_store<BM, BN>(lds, acc, epi, split, m0 + wm * (BM / 2), n0 + wn * (BN / 2), M, N, wave, lane);
+    epilogue_store<MT, NT>(lds, acc, epi, split, m0 + wm * (BM / 2), n0 + wn * (BN / 2), M, N, wave, lane);
+}
+
+// ---- 256 x 128 workgroup tile, 8 waves, 3-stage LDS ring ------------------------------------
+// One workgroup per CU (144 KiB of LDS).  The LDS-DMA of K tile t+2 is issued right after the
+// barrier that opens K tile t, so two tiles are always in flight and the barrier never drains the
+// DMA queue: waits are counted (s_waitcnt vmcnt(N) leaves the younger tile in flight) and the
+// barrier is a raw s_barrier.  A DMA'd tile is read only after its issuing waves' counted wait
+// AND a barrier; a ring slot is overwritten only after a barrier that every reader of its
+// previous contents has passed.
+#define VMCNT_BARRIER(N) do { asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)" ::: "memory"); \
+                              __builtin_amdgcn_s_barrier(); } while (0)
+
+template <bool AKM, bool BKM>
+__global__ void __launch_bounds__(512)
+k_gemm_bf16_w8(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, int M, int N, int K,
+               int tiles_m, int tiles_n, int k_per_split, Epi epi) {
+    constexpr int BM = 256, BN = 128, NW = 8, NS = 3;
+    typedef Tile<BM, AKM> TA;
+    typedef Tile<BN, BKM> TB;
+    constexpr int STAGE = TA::BYTES + TB::BYTES;         // 48 KiB
+    constexpr int MT = 4, NT = 4;                        // each wave: 64 x 64
+    constexpr int NIA = TA::template ni<NW>(), NIB = TB::template ni<NW>();
+    static_assert(NIA + NIB == 6, "the counted waits below assume 6 DMA instructions per wave and tile");
+    __shared__ __attribute__((aligned(1024))) char lds[NS * STAGE];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wm = wave >> 1, wn = wave & 1;
+    const int L = xcd_remap(blockIdx.x, gridDim.x);
+    const int tiles = tiles_m * tiles_n;
+    const int split = L / tiles, ti = L % tiles;
+    const int m0 = (ti / tiles_n) * BM, n0 = (ti % tiles_n) * BN;
+    const int kbeg = split * k_per_split;
+    const int kend = min(K, kbeg + k_per_split);
+    const int nk = kend > kbeg ? (kend - kbeg + GEMM_BK - 1) / GEMM_BK : 0;
+    const int nfull = kend > kbeg ? (kend - kbeg) / GEMM_BK : 0;      // tiles [0, nfull) come by DMA
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const bf16_t* sa[NIA];
+    const bf16_t* sb[NIB];
+    dma_setup<BM, AKM, NW>(A, lda, m0, M, wave, lane, sa);
+    dma_setup<BN, BKM, NW>(B, ldb, n0, N, wave, lane, sb);
+    const size_t ka = AKM ? 1 : (size_t)lda, kb = BKM ? 1 : (size_t)ldb;
+
+    auto issue = [&](int t) {
+        char* st = lds + (t % NS) * STAGE;
+        const int k0 = kbeg + t * GEMM_BK;
+        dma_issue<BM, AKM, NW>(sa, k0 * ka, st, wave);
+        dma_issue<BN, BKM, NW>(sb, k0 * kb, st + TA::BYTES, wave);
+    };
+    auto compute = [&](const char* la) {
+        const char* lb = la + TA::BYTES;
+        bf16x8_t fa[2][MT], fb[2][NT];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) fa[kk][i] = frag_read<BM, AKM>(la, wm * 64 + i * 16, kk, lane);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) fb[kk][j] = frag_read<BN, BKM>(lb, wn * 64 + j * 16, kk, lane);
+        }
+        __builtin_amdgcn_sched_barrier(0);     // all 16 fragment reads are issued before the first MFMA
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[kk][i], fb[kk][j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    // full K tiles: DMA only inside this loop (an ordinary register load in here would make the
+    // compiler drain the DMA queue every iteration)
+    if (nfull > 0) issue(0);
+    if (nfull > 1) issue(1);
+    for (int it = 0; it < nfull; ++it) {
+        // tile `it` must have landed; the 6 DMA instructions of tile it+1 stay in flight
+        if (it + 1 < nfull) VMCNT_BARRIER(6); else VMCNT_BARRIER(0);
+        if (it + 2 < nfull) issue(it + 2);
+        compute(lds + (it % NS) * STAGE);
+    }
+    // partial last K tile: through registers with zero fill, into ring slot 0
+    if (nk > nfull) {
+        VMCNT_BARRIER(0);
+        u32x4 ra[BM / (8 * NW)], rb[BN / (8 * NW)];
+        const int k0 = kbeg + nfull * GEMM_BK;
+        tile_load<BM, AKM, NW>(A, lda, m0, M, k0, kend, ra);
+        tile_load<BN, BKM, NW>(B, ldb, n0, N, k0, kend, rb);
+        tile_store<BM, AKM, NW>(lds, ra);
+        tile_store<BN, BKM, NW>(lds + TA::BYTES, rb);
+        VMCNT_BARRIER(0);
+        compute(lds);
+    }
+    VMCNT_BARRIER(0);        // every wave is done with the ring before it becomes the store staging area
+    epilogue_store<MT, NT>(lds, acc, epi, split, m0 + wm * 64, n0 + wn * 64, M, N, wave, lane);
 }
 
 // ---- fp32 / any-stride VALU kernel -----------------------------------------------
@@ -394,21 +495,34 @@ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 // tile choice shared by the launcher and the split-K hint: 128x128 workgroup tiles when the
 // output has enough of them, 64x64 otherwise; engine 2 / 3 force 64 / 128
-static inline int pick_tile(int M, int N, int engine) {
+static inline int pick_tile(int M, int N, int akm, int bkm, int engine) {
     if (engine == 2) return 64;
     if (engine == 3) return 128;
+    if (engine == 4) return 256;
     const long t128 = (long)ceil_div(M, 128) * ceil_div(N, 128);
+    const long t256 = (long)ceil_div(M, 256) * ceil_div(N, 128);
+    // 256 x 128 tiles (8 waves, 3-stage ring) measured faster for k-major products with many rows
+    if (akm && bkm && M >= 192 && N > 64 && t256 >= 40) return 256;
     return (M > 64 && N > 64 && t128 >= 40) ? 128 : 64;
 }
 
 static int launch_bf16(const void* A, int lda, int akm, const void* B, int ldb, int bkm, int M, int N, int K,
                        int splitk, int engine, const Epi& epi, hipStream_t stream) {
     int kps = ceil_div(ceil_div(K, splitk), GEMM_BK) * GEMM_BK;
-    const int bm = pick_tile(M, N, engine);
+    const int bm = pick_tile(M, N, akm, bkm, engine);
     const bool big = bm == 128;
-    const int tm = ceil_div(M, bm), tn = ceil_div(N, bm);
+    const int tm = ceil_div(M, bm), tn = ceil_div(N, bm == 256 ? 128 : bm);
     const unsigned grid = (unsigned)(tm * tn * splitk);
     const bf16_t* a = (const bf16_t*)A; const bf16_t* b = (const bf16_t*)B;
+    if (bm == 256) {
+#define LAUNCH8(AK, BK_) k_gemm_bf16_w8<AK, BK_><<<grid, 512, 0, stream>>>(a, lda, b, ldb, M, N, K, tm, tn, kps, epi)
+        if (akm && bkm) LAUNCH8(true, true);
+        else if (akm && !bkm) LAUNCH8(true, false);
+        else if (!akm && bkm) LAUNCH8(false, true);
+        else LAUNCH8(false, false);
+#undef LAUNCH8
+        return 0;
+    }
 #define LAUNCH(BMV, AK, BK_)                                                                         \
     k_gemm_bf16<BMV, BMV, AK, BK_><<<grid, 256, 0, stream>>>(a, lda, b, ldb, M, N, K, tm, tn, kps, epi)
     if (big) {
@@ -460,10 +574,10 @@ extern "C" {
 
 // K splits that give about two workgroups per CU for products with few output tiles,
 // keeping at least 4 (128-tile) / 4 (64-tile) K steps of 64 per split
-int vqa_gemm_splitk_hint(int M, int N, int K) {
-    const int bm = pick_tile(M, N, 0);
-    const long tiles = (long)ceil_div(M, bm) * ceil_div(N, bm);
-    int s = (int)(512 / tiles);                 // at most two workgroups per CU in one round
+int vqa_gemm_splitk_hint(int M, int N, int K, int a_kmajor, int b_kmajor) {
+    const int bm = pick_tile(M, N, a_kmajor, b_kmajor, 0);
+    const long tiles = (long)ceil_div(M, bm) * ceil_div(N, bm == 256 ? 128 : bm);
+    int s = (int)((bm == 256 ? 256 : 512) / tiles);   // one round of workgroups: 1 per CU (256 tiles) or 2 per CU
     const int maxs = K / 256 > 0 ? K / 256 : 1;
     if (s > maxs) s = maxs;
     if (s > 32) s = 32;

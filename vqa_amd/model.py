@@ -323,7 +323,7 @@ class VQAAttnModel(nn.Module):
     # ------------------------------------------------------------------ kernel helpers
     def _gemm_slabs(self, A, lda, akm, Bm, ldb, bkm, M, N, K):
         """fp32 partial sums of A B^T into the slab workspace -> (slab tensor, nslab, stride)."""
-        sk = call('vqa_gemm_splitk_hint', M, N, K)
+        sk = call('vqa_gemm_splitk_hint', M, N, K, akm, bkm)
         stride = M * N
         slab = self._slabs(sk * stride, A.device)
         call('vqa_gemm_slabs', ptr(A), lda, akm, ptr(Bm), ldb, bkm, ptr(slab), stride, N, M, N, K, sk,
