@@ -51,35 +51,57 @@ __global__ void k_embedding_gather(const int64_t* __restrict__ tok, const T* __r
 // (xg_t already holds x_t W_ih^T + b_ih + b_hh), order i, f, g, o.
 // Writes c (fp32, in place), h (T, operand of the next step's GEMM) and, for
 // rows whose last valid token is this step, q (fp32 and T).
+template <typename T> struct Vec4;
+template <> struct Vec4<float> {
+    static __device__ __forceinline__ f32x4 load(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+    static __device__ __forceinline__ void store(float* p, const f32x4& v) { *reinterpret_cast<f32x4*>(p) = v; }
+};
+template <> struct Vec4<bf16_t> {
+    static __device__ __forceinline__ f32x4 load(const bf16_t* p) {
+        const u16x4 r = *reinterpret_cast<const u16x4*>(p);
+        return f32x4{bf16_to_f32(r[0]), bf16_to_f32(r[1]), bf16_to_f32(r[2]), bf16_to_f32(r[3])};
+    }
+    static __device__ __forceinline__ void store(bf16_t* p, const f32x4& v) {
+        *reinterpret_cast<u16x4*>(p) = u16x4{f32_to_bf16(v[0]), f32_to_bf16(v[1]), f32_to_bf16(v[2]), f32_to_bf16(v[3])};
+    }
+};
+
+// 4 consecutive hidden units per thread (H % 4 == 0, leading dimensions % 4 == 0): 16-byte slab loads
 template <typename T>
-__global__ void k_lstm_cell(const float* __restrict__ slabs, int nslab, size_t slab_stride,
+__global__ void __launch_bounds__(256) k_lstm_cell(const float* __restrict__ slabs, int nslab, size_t slab_stride,
                             const T* __restrict__ xg, int ld_xg, float* __restrict__ c,
                             T* __restrict__ h, int ld_h, const int* __restrict__ len,
                             float* __restrict__ q32, T* __restrict__ qT, int ld_q,
                             int B, int H, int t, int L) {
-    const long total = (long)B * H;
+    const int H4 = H >> 2;
+    const long total = (long)B * H4;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int b = (int)(i / H), j = (int)(i % H);
-        float g[4];
+        const int b = (int)(i / H4), j = (int)(i % H4) * 4;
+        f32x4 g[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) g[k] = to_f32<T>(xg[(size_t)b * ld_xg + k * H + j]);
+        for (int k = 0; k < 4; ++k) g[k] = Vec4<T>::load(xg + (size_t)b * ld_xg + k * H + j);
         for (int s = 0; s < nslab; ++s) {
-            const float* sl = slabs + s * slab_stride + (size_t)b * 4 * H;
+            const float* sl = slabs + s * slab_stride + (size_t)b * 4 * H + j;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) g[k] += sl[k * H + j];
+            for (int k = 0; k < 4; ++k) g[k] += Vec4<float>::load(sl + k * H);
         }
-        const float ig = Act<T>::sigm_(g[0]), fg = Act<T>::sigm_(g[1]);
-        const float gg = Act<T>::tanh_(g[2]), og = Act<T>::sigm_(g[3]);
-        const float cprev = (t == 0) ? 0.f : c[i];
-        const float cn = fg * cprev + ig * gg;
-        const float hn = og * Act<T>::tanh_(cn);
-        c[i] = cn;
-        h[(size_t)b * ld_h + j] = from_f32<T>(hn);
+        f32x4 cprev = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (t != 0) cprev = Vec4<float>::load(c + (size_t)b * H + j);
+        f32x4 cn, hn;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float ig = Act<T>::sigm_(g[0][e]), fg = Act<T>::sigm_(g[1][e]);
+            const float gg = Act<T>::tanh_(g[2][e]), og = Act<T>::sigm_(g[3][e]);
+            cn[e] = fg * cprev[e] + ig * gg;
+            hn[e] = og * Act<T>::tanh_(cn[e]);
+        }
+        Vec4<float>::store(c + (size_t)b * H + j, cn);
+        Vec4<T>::store(h + (size_t)b * ld_h + j, hn);
         int last = len[b] - 1;
         if (last < 0) last += L;               // all-pad row: negative index -> last step
         if (last == t) {
-            q32[(size_t)b * ld_q + j] = hn;
-            qT[(size_t)b * ld_q + j] = from_f32<T>(hn);
+            Vec4<float>::store(q32 + (size_t)b * ld_q + j, hn);
+            Vec4<T>::store(qT + (size_t)b * ld_q + j, hn);
         }
     }
 }
@@ -122,19 +144,54 @@ __global__ void k_caption_pool(const int64_t* __restrict__ cap, const T* __restr
 template <typename T>
 __global__ void __launch_bounds__(256) k_inv_norm(const T* __restrict__ V, float* __restrict__ inv_norm,
                                                   long rows, int Dv, int ldV) {
+    // each wave walks rows wave_id, wave_id + n_waves, ...; the loads of the next row are issued
+    // before the current row is reduced (all loads unconditional: indices are clamped)
     const int lane = threadIdx.x & 63;
-    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const T* p = V + (size_t)row * ldV;
-    float ss = 0.f;
-    for (int v = lane; v < (Dv >> 3); v += 64) {
-        float x[8];
-        Vec8<T>::load(p + v * 8, x);
+    const long nw = (long)gridDim.x * 4, w0 = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nv = Dv >> 3;
+    if (nv <= 256) {
+        int voff[4];
+        float live[4];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) ss += x[i] * x[i];
+        for (int i = 0; i < 4; ++i) { const int v = lane + 64 * i; voff[i] = min(v, nv - 1) * 8; live[i] = v < nv ? 1.f : 0.f; }
+        float cur[4][8], nxt[4][8];
+        if (w0 < rows) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) Vec8<T>::load(V + (size_t)w0 * ldV + voff[i], cur[i]);
+        }
+        for (long row = w0; row < rows; row += nw) {
+            const long rn = row + nw < rows ? row + nw : rows - 1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) Vec8<T>::load(V + (size_t)rn * ldV + voff[i], nxt[i]);
+            float ss = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float a = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a += cur[i][e] * cur[i][e];
+                ss += a * live[i];
+            }
+            ss = wave_sum(ss);
+            if (lane == 0) inv_norm[row] = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) cur[i][e] = nxt[i][e];
+        }
+    } else {
+        for (long row = w0; row < rows; row += nw) {
+            const T* p = V + (size_t)row * ldV;
+            float ss = 0.f;
+            for (int v = lane; v < nv; v += 64) {
+                float x[8];
+                Vec8<T>::load(p + v * 8, x);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) ss += x[i] * x[i];
+            }
+            ss = wave_sum(ss);
+            if (lane == 0) inv_norm[row] = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+        }
     }
-    ss = wave_sum(ss);
-    if (lane == 0) inv_norm[row] = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
 }
 
 // ---------------------------------------------------------------------------
@@ -424,8 +481,10 @@ int vqa_lstm_cell(const float* slabs, int nslab, size_t slab_stride, const void*
                   int B, int H, int t, int L, int dtype, hipStream_t stream) {
     VQA_REQUIRE(xg_t && c && h && lengths && q_f32 && q_t && (nslab == 0 || slabs), "vqa_lstm_cell: null pointer");
     VQA_REQUIRE(B >= 0 && H > 0 && t >= 0 && t < L && ld_xg >= 4 * H && ld_h >= H && ld_q >= H, "vqa_lstm_cell: bad sizes");
+    VQA_REQUIRE(H % 4 == 0 && ld_xg % 4 == 0 && ld_h % 4 == 0 && ld_q % 4 == 0 && (slab_stride % 4 == 0 || nslab <= 1),
+                "vqa_lstm_cell: H and leading dimensions must be multiples of 4");
     if (B == 0) return 0;
-    DISPATCH_T(dtype, (k_lstm_cell<T><<<grid_for((long)B * H, 256), 256, 0, stream>>>(
+    DISPATCH_T(dtype, (k_lstm_cell<T><<<grid_for((long)B * (H / 4), 256), 256, 0, stream>>>(
         slabs, nslab, slab_stride, (const T*)xg_t, ld_xg, c, (T*)h, ld_h, lengths, q_f32, (T*)q_t, ld_q, B, H, t, L)));
     return vqa_check_launch("vqa_lstm_cell");
 }
@@ -444,7 +503,7 @@ int vqa_inv_norm(const void* V, float* inv_norm, long rows, int Dv, int ldV, int
     VQA_REQUIRE(V && inv_norm && rows >= 0 && Dv > 0, "vqa_inv_norm: bad arguments");
     VQA_REQUIRE(Dv % 8 == 0 && ldV % 8 == 0 && ldV >= Dv, "vqa_inv_norm: Dv and ldV must be multiples of 8");
     if (rows == 0) return 0;
-    DISPATCH_T(dtype, (k_inv_norm<T><<<(unsigned)((rows + 3) / 4), 256, 0, stream>>>((const T*)V, inv_norm, rows, Dv, ldV)));
+    DISPATCH_T(dtype, (k_inv_norm<T><<<(unsigned)((rows + 3) / 4 < 2048 ? (rows + 3) / 4 : 2048), 256, 0, stream>>>((const T*)V, inv_norm, rows, Dv, ldV)));
     return vqa_check_launch("vqa_inv_norm");
 }
 
