@@ -352,21 +352,26 @@ k_gemm_bf16(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B,
 #define VMCNT_BARRIER(N) do { asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)" ::: "memory"); \
                               __builtin_amdgcn_s_barrier(); } while (0)
 
-template <bool AKM, bool BKM>
+template <bool AKM, bool BKM, int BN>
 __global__ void __launch_bounds__(512)
 k_gemm_bf16_w8(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, int M, int N, int K,
                int tiles_m, int tiles_n, int k_per_split, Epi epi) {
-    constexpr int BM = 256, BN = 128, NW = 8, NS = 3;
+    // BN = 128: waves 4 (M) x 2 (N), 64 x 64 each, 3 ring slots of 48 KiB (two K tiles in flight)
+    // BN = 256: waves 2 (M) x 4 (N), 128 x 64 each, 2 ring slots of 64 KiB (one K tile in flight):
+    //           a third less operand traffic per flop
+    constexpr int BM = 256, NW = 8, NS = BN == 128 ? 3 : 2;
     typedef Tile<BM, AKM> TA;
     typedef Tile<BN, BKM> TB;
-    constexpr int STAGE = TA::BYTES + TB::BYTES;         // 48 KiB
-    constexpr int MT = 4, NT = 4;                        // each wave: 64 x 64
+    constexpr int STAGE = TA::BYTES + TB::BYTES;
+    constexpr int WAVES_N = BN / 64, WAVES_M = NW / WAVES_N, WMR = BM / WAVES_M;   // rows per wave
+    constexpr int MT = WMR / 16, NT = 4;
     constexpr int NIA = TA::template ni<NW>(), NIB = TB::template ni<NW>();
-    static_assert(NIA + NIB == 6, "the counted waits below assume 6 DMA instructions per wave and tile");
+    constexpr int EPI_BYTES = NW * 32 * (64 + 4) * 4;
+    static_assert(NS * STAGE >= EPI_BYTES, "ring must hold the store staging area");
     __shared__ __attribute__((aligned(1024))) char lds[NS * STAGE];
 
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wm = wave >> 1, wn = wave & 1;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int L = xcd_remap(blockIdx.x, gridDim.x);
     const int tiles = tiles_m * tiles_n;
     const int split = L / tiles, ti = L % tiles;
@@ -396,34 +401,60 @@ k_gemm_bf16_w8(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__
     };
     auto compute = [&](const char* la) {
         const char* lb = la + TA::BYTES;
-        bf16x8_t fa[2][MT], fb[2][NT];
+        if (MT <= 4) {
+            bf16x8_t fa[2][MT], fb[2][NT];
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+            for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
-            for (int i = 0; i < MT; ++i) fa[kk][i] = frag_read<BM, AKM>(la, wm * 64 + i * 16, kk, lane);
+                for (int i = 0; i < MT; ++i) fa[kk][i] = frag_read<BM, AKM>(la, wm * WMR + i * 16, kk, lane);
 #pragma unroll
-            for (int j = 0; j < NT; ++j) fb[kk][j] = frag_read<BN, BKM>(lb, wn * 64 + j * 16, kk, lane);
-        }
-        __builtin_amdgcn_sched_barrier(0);     // all 16 fragment reads are issued before the first MFMA
+                for (int j = 0; j < NT; ++j) fb[kk][j] = frag_read<BN, BKM>(lb, wn * 64 + j * 16, kk, lane);
+            }
+            __builtin_amdgcn_sched_barrier(0);     // all fragment reads are issued before the first MFMA
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+            for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
+                for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[kk][i], fb[kk][j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[kk][i], fb[kk][j], acc[i][j], 0, 0, 0);
+            }
+        } else {
+            // 128 x 64 per wave: fragments of one K sub-step at a time (register budget)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8_t fa[MT], fb[NT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) fa[i] = frag_read<BM, AKM>(la, wm * WMR + i * 16, kk, lane);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) fb[j] = frag_read<BN, BKM>(lb, wn * 64 + j * 16, kk, lane);
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            }
         }
     };
 
     // full K tiles: DMA only inside this loop (an ordinary register load in here would make the
     // compiler drain the DMA queue every iteration)
     if (nfull > 0) issue(0);
-    if (nfull > 1) issue(1);
-    for (int it = 0; it < nfull; ++it) {
-        // tile `it` must have landed; the 6 DMA instructions of tile it+1 stay in flight
-        if (it + 1 < nfull) VMCNT_BARRIER(6); else VMCNT_BARRIER(0);
-        if (it + 2 < nfull) issue(it + 2);
-        compute(lds + (it % NS) * STAGE);
+    if (NS == 3) {
+        static_assert(BN != 128 || NIA + NIB == 6, "the counted wait assumes 6 DMA instructions per wave and tile");
+        if (nfull > 1) issue(1);
+        for (int it = 0; it < nfull; ++it) {
+            // tile `it` must have landed; the 6 DMA instructions of tile it+1 stay in flight
+            if (it + 1 < nfull) VMCNT_BARRIER(6); else VMCNT_BARRIER(0);
+            if (it + 2 < nfull) issue(it + 2);
+            compute(lds + (it % NS) * STAGE);
+        }
+    } else {
+        for (int it = 0; it < nfull; ++it) {
+            VMCNT_BARRIER(0);                      // tile `it` landed; every wave is done with the other slot
+            if (it + 1 < nfull) issue(it + 1);
+            compute(lds + (it % NS) * STAGE);
+        }
     }
     // partial last K tile: through registers with zero fill, into ring slot 0
     if (nk > nfull) {
@@ -438,7 +469,7 @@ k_gemm_bf16_w8(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__
         compute(lds);
     }
     VMCNT_BARRIER(0);        // every wave is done with the ring before it becomes the store staging area
-    epilogue_store<MT, NT>(lds, acc, epi, split, m0 + wm * 64, n0 + wn * 64, M, N, wave, lane);
+    epilogue_store<MT, NT>(lds, acc, epi, split, m0 + wm * WMR, n0 + wn * 64, M, N, wave, lane);
 }
 
 // ---- fp32 / any-stride VALU kernel -----------------------------------------------
@@ -495,27 +526,36 @@ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 // tile choice shared by the launcher and the split-K hint: 128x128 workgroup tiles when the
 // output has enough of them, 64x64 otherwise; engine 2 / 3 force 64 / 128
-static inline int pick_tile(int M, int N, int akm, int bkm, int engine) {
+static inline int pick_tile(int M, int N, int K, int akm, int bkm, int engine) {
     if (engine == 2) return 64;
     if (engine == 3) return 128;
     if (engine == 4) return 256;
+    if (engine == 6) return 512;                          // 256 x 256 tiles
     const long t128 = (long)ceil_div(M, 128) * ceil_div(N, 128);
     const long t256 = (long)ceil_div(M, 256) * ceil_div(N, 128);
-    // 256 x 128 tiles (8 waves, 3-stage ring) measured faster for k-major products with many rows
-    if (akm && bkm && M >= 192 && N > 64 && t256 >= 40) return 256;
+    const long t512 = (long)ceil_div(M, 256) * ceil_div(N, 256);
+    // measured on MI355X: these products are bound by the per-CU operand fetch rate, so the
+    // largest tile that still gives every CU a workgroup wins
+    // (256 x 256 needs enough tiles, or enough K to split, to give most CUs a workgroup)
+    const long split512 = t512 >= 200 ? 1 : (K / 256 < 256 / t512 ? K / 256 : 256 / t512);
+    if (M >= 384 && N >= 192 && t512 >= 32 && t512 * split512 >= 192) return 512;       // 256 x 256 tiles
+    if (akm && bkm && M >= 192 && N > 64 && t256 >= 40) return 256;   // 256 x 128 tiles, 3-stage ring
     return (M > 64 && N > 64 && t128 >= 40) ? 128 : 64;
 }
 
 static int launch_bf16(const void* A, int lda, int akm, const void* B, int ldb, int bkm, int M, int N, int K,
                        int splitk, int engine, const Epi& epi, hipStream_t stream) {
     int kps = ceil_div(ceil_div(K, splitk), GEMM_BK) * GEMM_BK;
-    const int bm = pick_tile(M, N, akm, bkm, engine);
+    const int bm = pick_tile(M, N, K, akm, bkm, engine);
     const bool big = bm == 128;
-    const int tm = ceil_div(M, bm), tn = ceil_div(N, bm == 256 ? 128 : bm);
+    const int bmr = bm >= 256 ? 256 : bm, bnr = bm == 512 ? 256 : (bm == 256 ? 128 : bm);
+    const int tm = ceil_div(M, bmr), tn = ceil_div(N, bnr);
     const unsigned grid = (unsigned)(tm * tn * splitk);
     const bf16_t* a = (const bf16_t*)A; const bf16_t* b = (const bf16_t*)B;
-    if (bm == 256) {
-#define LAUNCH8(AK, BK_) k_gemm_bf16_w8<AK, BK_><<<grid, 512, 0, stream>>>(a, lda, b, ldb, M, N, K, tm, tn, kps, epi)
+    if (bm >= 256) {
+#define LAUNCH8(AK, BK_)                                                                                             \
+    do { if (bm == 256) k_gemm_bf16_w8<AK, BK_, 128><<<grid, 512, 0, stream>>>(a, lda, b, ldb, M, N, K, tm, tn, kps, epi); \
+         else k_gemm_bf16_w8<AK, BK_, 256><<<grid, 512, 0, stream>>>(a, lda, b, ldb, M, N, K, tm, tn, kps, epi); } while (0)
         if (akm && bkm) LAUNCH8(true, true);
         else if (akm && !bkm) LAUNCH8(true, false);
         else if (!akm && bkm) LAUNCH8(false, true);
@@ -575,9 +615,9 @@ extern "C" {
 // K splits that give about two workgroups per CU for products with few output tiles,
 // keeping at least 4 (128-tile) / 4 (64-tile) K steps of 64 per split
 int vqa_gemm_splitk_hint(int M, int N, int K, int a_kmajor, int b_kmajor) {
-    const int bm = pick_tile(M, N, a_kmajor, b_kmajor, 0);
-    const long tiles = (long)ceil_div(M, bm) * ceil_div(N, bm == 256 ? 128 : bm);
-    int s = (int)((bm == 256 ? 256 : 512) / tiles);   // one round of workgroups: 1 per CU (256 tiles) or 2 per CU
+    const int bm = pick_tile(M, N, K, a_kmajor, b_kmajor, 0);
+    const long tiles = (long)ceil_div(M, bm >= 256 ? 256 : bm) * ceil_div(N, bm == 512 ? 256 : (bm == 256 ? 128 : bm));
+    int s = (int)((bm >= 256 ? 256 : 512) / tiles);   // one round of workgroups: 1 per CU (256 tiles) or 2 per CU
     const int maxs = K / 256 > 0 ? K / 256 : 1;
     if (s > maxs) s = maxs;
     if (s > 32) s = 32;
