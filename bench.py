@@ -104,6 +104,7 @@ def main():
 
     for i in range(args.warmup):
         step(i)
+    model.sync()                      # no deferred update of the warmup leaks into the timed region
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -112,6 +113,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = step(args.warmup + i)
+    model.sync()                      # the K-th step's deferred last-bucket all-reduce + Adam is timed too
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -204,6 +204,66 @@ def test_train_step_matches_oracle_adam():
         assert rel_err(sd[k], po[k]) <= 2e-5, k
 
 
+class _LoopbackReducer:
+    """One-rank stand-in for GradReducer with the deferral switched on: the collective is the
+    identity, so parameters must come out bit-identical to the reducer-less step."""
+    enabled, defer_last, world = True, True, 1
+
+    def __init__(self):
+        self.fired, self.last_waited = [], 0
+
+    def begin(self, model):
+        self.fired = []
+
+    def bucket_ready(self, index):
+        self.fired.append(index)
+
+    def finish(self, defer_last=False):
+        self.deferred = defer_last
+        return 1.0
+
+    def finish_last(self):
+        self.last_waited += 1
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_deferred_last_bucket_is_exact(dtype):
+    """The last gradient bucket's Adam update is applied inside the next step (or by sync /
+    state_dict); every parameter ends bit-identical to the undeferred schedule."""
+    kw = MID
+    ma, _ = build(kw, 2, False, dtype)
+    mb, _ = build(kw, 2, False, dtype)
+    ma.train(), mb.train()
+    red = _LoopbackReducer()
+    lo, hi = None, None
+    for step in range(1, 4):
+        b = batch(kw, 16, 25, 14, seed=200 + step)
+        args = (b['feats'].cuda().to(dtype), b['tokens'].cuda(), b['answers'].cuda())
+        la = ma.train_step(*args, lr=1e-3)
+        lb = mb.train_step(*args, lr=1e-3, reducer=red)
+        assert torch.equal(la, lb)
+        lo, hi = mb.buckets[-1]
+        assert red.deferred and red.fired == list(range(len(mb.buckets)))
+        assert mb._pending is not None and red.last_waited == step - 1
+        torch.cuda.synchronize()    # the deferred slice is one update behind, the rest is current
+        assert torch.equal(mb._flat[:lo], ma._flat[:lo])
+        assert not torch.equal(mb._flat[lo:hi], ma._flat[lo:hi])
+    sd_a, sd_b = ma.state_dict(), mb.state_dict()        # state_dict() flushes the deferred update
+    assert mb._pending is None and red.last_waited == 3
+    for k in sd_a:
+        assert torch.equal(sd_a[k], sd_b[k]), k
+    if dtype == torch.bfloat16:
+        assert torch.equal(ma._shadow, mb._shadow)
+    # eval forward after a deferred step sees the flushed parameters
+    b = batch(kw, 16, 25, 14, seed=300)
+    args = (b['feats'].cuda().to(dtype), b['tokens'].cuda(), b['answers'].cuda())
+    ma.train_step(*args, lr=1e-3)
+    mb.train_step(*args, lr=1e-3, reducer=red)
+    ma.eval(), mb.eval()
+    with torch.no_grad():
+        assert torch.equal(ma(args[0], args[1]), mb(args[0], args[1]))
+
+
 def test_argmax_and_counts_bit_exact(golden_dir):
     from vqa_amd import _lib
     from vqa_amd._lib import call, ptr

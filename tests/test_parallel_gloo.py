@@ -44,6 +44,17 @@ def _worker(rank, world, port, out_dir):
     _, _, gfull = vqa_ref.loss_and_grads(p, full['feats'], full['tokens'], full['answers'])
     for k in order:
         assert torch.allclose(fm.views[k] * scale, gfull[k], rtol=1e-4, atol=1e-7), k
+    # deferred last bucket: finish(defer_last=True) leaves exactly that all-reduce in flight and
+    # finish_last() completes it; the reduced values are the same
+    fm2 = _FakeModel(g, order, cuts=[4, 8, len(order) - 1])
+    red.begin(fm2)
+    for i in range(len(fm2.buckets)):
+        red.bucket_ready(i)
+    assert red.finish(defer_last=True) == scale
+    assert len(red._handles) == 1
+    red.finish_last()
+    assert red._handles == []
+    assert torch.equal(fm2._flat_grad, fm._flat_grad)
     # accuracy counters: integer sums
     logits = vqa_ref.forward(p, full['feats'][sl], full['tokens'][sl])
     pred = vqa_ref.argmax_first(logits.numpy())

@@ -156,6 +156,7 @@ class VQAAttnModel(nn.Module):
         self._ctx = None
         self.grad_ready_hook = None   # callable(bucket_index) fired as gradient buckets complete
         self.kernel_events = None     # set to {} to collect per-kernel HIP event pairs
+        self._pending = None          # last gradient bucket of the previous train_step still in flight
 
     # ------------------------------------------------------------------ flat parameter storage
     def _trainable_order(self) -> List[Tuple[str, nn.Parameter]]:
@@ -428,13 +429,16 @@ class VQAAttnModel(nn.Module):
         Tc = captions.shape[1] if captions is not None else 0
         _lib.bind_stream()
         self._materialize(dev)
-        self._refresh_shadow()
         ws = self._workspace(B, R, L, Tc, dev)
         H, A, F, Hf, Ec, C, Cp, dt = self.Hq, self.A, self.F, self.Hf, self.Ec, self.num_classes, _pad8(self.num_classes), self.dt
         seeds, p = self._drop_seeds()
 
+        # parameter-independent prologue first: a gradient bucket still being all-reduced from the
+        # previous train_step (and its Adam update) is only needed from here on
         self.encode_question(tokens, ws)
         call('vqa_inv_norm', ptr(feats), ptr(ws['inv_norm']), B * R, Dv, Dv, dt)
+        self._finish_pending()
+        self._refresh_shadow()
         u32, uT = ws['q32'], ws['qT']
         for k in range(self.hops):
             pre = f'attention.{k}.'
@@ -556,23 +560,50 @@ class VQAAttnModel(nn.Module):
              ptr(counters))
         return ws['pred']
 
-    def adam_step(self, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, grad_scale: float = 1.0):
-        """One fused Adam update of every trainable parameter from the flat gradient buffer."""
+    def _adam_range(self, lo: int, hi: int, lr, betas, eps, step: int, grad_scale: float):
         if self._exp_avg is None:
             self._exp_avg = torch.zeros_like(self._flat)
             self._exp_avg_sq = torch.zeros_like(self._flat)
-        self.step_count += 1
+        if hi <= lo:
+            return
         _lib.bind_stream()
-        call('vqa_adam_step', ptr(self._flat), ptr(self._flat_grad), ptr(self._exp_avg), ptr(self._exp_avg_sq),
-             ptr(self._shadow), self._flat.numel(), lr, betas[0], betas[1], eps, self.step_count, grad_scale)
+        sh = None if self._shadow is None else self._shadow.data_ptr() + 2 * lo
+        call('vqa_adam_step', self._flat.data_ptr() + 4 * lo, self._flat_grad.data_ptr() + 4 * lo,
+             self._exp_avg.data_ptr() + 4 * lo, self._exp_avg_sq.data_ptr() + 4 * lo, sh, hi - lo, lr, betas[0], betas[1],
+             eps, step, grad_scale)
+
+    def adam_step(self, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, grad_scale: float = 1.0):
+        """One fused Adam update of every trainable parameter from the flat gradient buffer."""
+        self._finish_pending()
+        self.step_count += 1
+        self._adam_range(0, self._flat.numel(), lr, betas, eps, self.step_count, grad_scale)
         self._shadow_fresh = self.dt == _lib.BF16
         self._shadow_version = self._flat._version
 
+    def _finish_pending(self):
+        """Complete a train_step whose last gradient bucket was left in flight: wait for its
+        all-reduce and apply its Adam update."""
+        pend = self._pending
+        if pend is None:
+            return
+        self._pending = None
+        reducer, lo, hi, lr, betas, eps, step, scale = pend
+        reducer.finish_last()
+        self._adam_range(lo, hi, lr, betas, eps, step, scale)
+
+    def sync(self):
+        """Make every parameter current (applies a deferred last-bucket update, if any)."""
+        self._finish_pending()
+
     def train_step(self, input_v, input_q, answers, captions=None, lr: float = 1e-5, reducer=None) -> torch.Tensor:
         """forward + loss + backward (+ gradient all-reduce through `reducer`) + Adam
-        (train.py:200-204 in one call).  Returns the loss as a 1-element device tensor."""
+        (train.py:200-204 in one call).  Returns the loss as a 1-element device tensor.
+        With a reducer whose `defer_last` is set, the all-reduce and Adam update of the last
+        gradient bucket are completed inside the next call (after its question-encoder / inv-norm
+        prologue, which they do not affect) or by sync(); results are identical either way."""
         feats, tokens, captions = self._prepare_inputs(input_v, input_q, captions)
         self._materialize(feats.device)
+        betas, eps = (0.9, 0.999), 1e-8
         with torch.no_grad():
             self._forward_impl(feats, tokens, captions)
             loss = self.loss_and_grad_logits(answers)
@@ -583,14 +614,26 @@ class VQAAttnModel(nn.Module):
                 self._backward_impl()
             finally:
                 self.grad_ready_hook = None
-            scale = 1.0
-            if reducer is not None:
-                scale = reducer.finish()
-            self.adam_step(lr, grad_scale=scale)
+            if reducer is not None and reducer.enabled and reducer.defer_last and len(self.buckets) > 1:
+                scale = reducer.finish(defer_last=True)
+                lo, hi = self.buckets[-1]
+                self.step_count += 1
+                self._adam_range(0, lo, lr, betas, eps, self.step_count, scale)
+                self._pending = (reducer, lo, hi, lr, betas, eps, self.step_count, scale)
+                self._shadow_fresh = self.dt == _lib.BF16
+                self._shadow_version = self._flat._version
+            else:
+                scale = reducer.finish() if reducer is not None else 1.0
+                self.adam_step(lr, betas, eps, grad_scale=scale)
         return loss
 
     # ------------------------------------------------------------------ torch plumbing
+    def state_dict(self, *a, **kw):
+        self._finish_pending()
+        return super().state_dict(*a, **kw)
+
     def _apply(self, fn, *a, **kw):
+        self._finish_pending()
         out = super()._apply(fn, *a, **kw)
         self._flat = None               # parameters moved: rebuild the flat views lazily
         self._frozen_key = None
@@ -599,6 +642,7 @@ class VQAAttnModel(nn.Module):
         return out
 
     def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        self._finish_pending()
         out = super().load_state_dict(state_dict, strict=strict, **kw)
         self._shadow_fresh = False
         self._frozen_key = None

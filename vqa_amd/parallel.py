@@ -21,8 +21,11 @@ import torch.distributed as dist
 
 
 class GradReducer:
-    def __init__(self, process_group: Optional["dist.ProcessGroup"] = None):
+    def __init__(self, process_group: Optional["dist.ProcessGroup"] = None, defer_last: bool = True):
         self.group = process_group
+        # the last bucket (the image projection) only completes at the very end of backward: its
+        # all-reduce is left running under the next step's parameter-independent prologue
+        self.defer_last = defer_last
         self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1
         self.world = dist.get_world_size(process_group) if self.enabled else 1
         self._handles: List = []
@@ -48,16 +51,26 @@ class GradReducer:
         self._handles.append(dist.all_reduce(self._flat_grad[s:e], op=dist.ReduceOp.SUM, group=self.group,
                                              async_op=True))
 
-    def finish(self) -> float:
-        """Wait for every bucket (reducing any that was never signalled) and return the
-        factor that turns the summed gradients into the global-batch mean."""
+    def finish(self, defer_last: bool = False) -> float:
+        """Wait for every bucket (reducing any that was never signalled) -- all but the last one
+        when `defer_last` -- and return the factor that turns the summed gradients into the
+        global-batch mean."""
         for i, done in enumerate(self._fired):
             if not done:
                 self.bucket_ready(i)
+        keep = []
+        if defer_last and self.enabled and len(self._handles) == len(self._buckets):
+            keep = [self._handles.pop()]           # handles are in bucket order
+        for h in self._handles:
+            h.wait()
+        self._handles = keep
+        return 1.0 / self.world
+
+    def finish_last(self) -> None:
+        """Wait for the bucket left in flight by finish(defer_last=True)."""
         for h in self._handles:
             h.wait()
         self._handles = []
-        return 1.0 / self.world
 
 
 def reduce_counters(counters: torch.Tensor, process_group=None) -> torch.Tensor:
