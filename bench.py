@@ -72,8 +72,8 @@ def cpu_baseline(B, R, Dv, L, Vq, C, threads):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=30)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--batch', type=int, default=256, help='per-GPU batch')
     ap.add_argument('--regions', type=int, default=196)
     ap.add_argument('--hops', type=int, default=1)
