@@ -88,6 +88,33 @@ int vqa_attn_bwd(const void* P, int ldP, const void* V, int ldV, const float* qa
                  float* dqa_f32, void* dqa_t, int ld_dqa, float* dwa_part, float* dc_part, int B, int R, int A, int Dv,
                  int dtype, hipStream_t stream);
 
+/* ---- feature-map front-ends of the reference's ResNet models (precomputed maps) ------------- */
+
+/* out[b, col0 + c] = mean over the H*W grid of channel c      model.py:161-164 (torch.mean(x, axis=(2,3)))
+ * layout 0: x is (B, C, HW) (an NCHW map); layout 1: x is (B, HW, C), C % 8 == 0.
+ * In layout 1 the grid may be split into nsplit row ranges (vqa_grid_mean_splits tells how many keep
+ * the chip busy); partial then holds nsplit * B * C floats.  The summation order is fixed. */
+int vqa_grid_mean_splits(int layout, int B, int C, int HW);
+int vqa_grid_mean(const void* x, int layout, int B, int C, int HW, float* out, int ld_out, int col0,
+                  float* partial, int nsplit, int dtype, hipStream_t stream);
+
+/* gate[b,n] = sigmoid(sum_s slabs[s][b][n] + bias[n]);  out[b,n] = dropout(mean[b,n] * gate[b,n])
+ *                     model.py:125-140 (gapK = Linear + Sigmoid), 166-172 (product, cat, dropoutV) */
+int vqa_gate_fwd(const float* slabs, int nslab, size_t slab_stride, const float* bias, const float* mean, int ld_mean,
+                 float* gate, int ld_gate, void* out, int ld_out, int B, int N, unsigned seed, float p, int dtype,
+                 hipStream_t stream);
+/* dz[b,n] = d_out[b,n] * mean[b,n] * gate (1 - gate): gradient at the gate's pre-activation */
+int vqa_gate_bwd(const float* d_out, int ld_d, const float* mean, int ld_mean, const float* gate, int ld_gate,
+                 void* dz, int ld_dz, int B, int N, int dtype, hipStream_t stream);
+
+/* out[b, ch * R + r] = dropout(y[b * R + r, ch]): the NCHW .view(-1, VISUAL_OUT) of the 1x1-convolved
+ * map followed by dropoutV                                              model.py:54, 61-62 */
+int vqa_flatten_cm(const void* y, int ld_y, void* out, int ld_out, int B, int R, int c, unsigned seed, float p,
+                   int dtype, hipStream_t stream);
+/* dy[b * R + r, ch] = d_out[b, ch * R + r] for ch < c, 0 for c <= ch < ld_dy (backward of the above) */
+int vqa_unflatten_cm(const float* d_out, int ld_d, void* dy, int ld_dy, int B, int R, int c, int dtype,
+                     hipStream_t stream);
+
 /* ---- GEMM:  C[M,N] = sum_k A(m,k) B(n,k) ------------------------------------
  * a_kmajor / b_kmajor: 1 when the operand is stored with k contiguous ([M][K], [N][K] as an
  * nn.Linear weight), 0 when stored [K][M] / [K][N].  engine: 0 = MFMA for bf16 (fp32 always

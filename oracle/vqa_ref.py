@@ -11,6 +11,8 @@ reference lines it follows (paths relative to the reference checkout):
 
 * question encoder   vqa_model/models/seq2vec.py:11-45
 * region pooling     vqa_model/models/model.py:161-164   (uniform special case)
+* gated GAP model    vqa_model/models/model.py:125-140, 149-184
+* conv-flatten model vqa_model/models/model.py:53-54, 60-79
 * fusion head        vqa_model/models/model.py:60-79
 * caption stream     vqa_model/models/model.py:1571-1574, 1678, 1734-1741
 * loss / optimiser   vqa_model/train.py:34-35, 201-204
@@ -159,11 +161,33 @@ def caption_vector(cap_tokens, table) -> torch.Tensor:
     return l2_normalise(pooled)
 
 
-def forward(p: Dict[str, torch.Tensor], feats: torch.Tensor, tokens: torch.Tensor,
+def gated_gap(maps: Sequence[torch.Tensor], q: torch.Tensor, p: Dict[str, torch.Tensor]) -> torch.Tensor:
+    """VQAGAPModel's visual vector: for each ResNet stage k = 1..4 the mean of the (B, C_k, H_k, W_k)
+    map over its grid (model.py:161-164) times the question gate sigmoid(gap_k(q)) (model.py:125-140,
+    166-169, on the un-dropped question vector), concatenated (model.py:171)."""
+    parts = []
+    for k, m in enumerate(maps, 1):
+        avg = m.mean(dim=(2, 3))
+        gate = torch.sigmoid(q @ p[f'gap{k}.0.weight'].t() + p[f'gap{k}.0.bias'])
+        parts.append(avg * gate)
+    return torch.cat(parts, dim=1)
+
+
+def conv_flatten(fmap: torch.Tensor, p: Dict[str, torch.Tensor]) -> torch.Tensor:
+    """VQAModel's visual vector: Conv2d(Dv, Dv / (H W), 1) over the last ResNet map (model.py:53-54)
+    then .view(-1, VISUAL_OUT) of the NCHW result (model.py:61): channel-major flatten."""
+    w = p['visual.1.weight']
+    y = torch.einsum('bkhw,ck->bchw', fmap, w.reshape(w.shape[0], w.shape[1])) + p['visual.1.bias'][None, :, None, None]
+    return y.reshape(fmap.shape[0], -1)
+
+
+def forward(p: Dict[str, torch.Tensor], feats, tokens: torch.Tensor,
             captions: Optional[torch.Tensor] = None, hops: int = 1,
             drop_seeds: Optional[Sequence[int]] = None, drop_p: float = 0.5,
-            return_aux: bool = False):
-    """feats (B, R, Dv) float; tokens (B, L) int64 -> logits (B, C).
+            return_aux: bool = False, mode: str = 'attn'):
+    """mode 'attn': feats (B, R, Dv) region features; mode 'gap': feats = the four (B, C_k, H_k, W_k)
+    stage maps of VQAGAPModel; mode 'conv': feats = the (B, Dv, H, W) map of VQAModel.
+    tokens (B, L) int64 -> logits (B, C).
 
     Head verbatim from model.py:62-77: x_v = tanh(linear_v(drop(pooled)));
     x_q = tanh(linear_q(drop(q))); x = drop(tanh(x_v * x_q));
@@ -172,10 +196,18 @@ def forward(p: Dict[str, torch.Tensor], feats: torch.Tensor, tokens: torch.Tenso
     """
     ds = drop_seeds if drop_seeds is not None else (None, None, None, None)
     q = encode_question(tokens, p)
-    v_hat = l2_normalise(feats)
     u = q
     att = []
     pooled = None
+    v_hat = None
+    if mode == 'gap':
+        pooled = gated_gap(feats, q, p)
+        hops = 0
+    elif mode == 'conv':
+        pooled = conv_flatten(feats, p)
+        hops = 0
+    else:
+        v_hat = l2_normalise(feats)
     for k in range(hops):
         pre = f'attention.{k}.'
         pooled, pk = attention_hop(v_hat, u, p[pre + 'linear_va.weight'], p[pre + 'linear_va.bias'],
@@ -258,7 +290,8 @@ def oa_aa(count: np.ndarray, right: np.ndarray):
 
 def init_params(vq: int, C: int, E: int, Hq: int, Dv: int, A: int, F: int, Hf: int,
                 hops: int = 1, vc: int = 0, Ec: int = 0, seed: int = 0,
-                dtype=torch.float32) -> Dict[str, torch.Tensor]:
+                dtype=torch.float32, mode: str = 'attn', gap_channels: Sequence[int] = (),
+                conv_out: int = 0) -> Dict[str, torch.Tensor]:
     """Random parameters with the reference's shapes and state_dict key names
     (model.py:44, 55-58; seq2vec.py:35-38).  nn.Linear / nn.LSTM / nn.Embedding
     default initialisers."""
@@ -281,7 +314,15 @@ def init_params(vq: int, C: int, E: int, Hq: int, Dv: int, A: int, F: int, Hf: i
     p['seq2vec.rnn.weight_hh_l0'] = uni((4 * Hq, Hq), k)
     p['seq2vec.rnn.bias_ih_l0'] = uni((4 * Hq,), k)
     p['seq2vec.rnn.bias_hh_l0'] = uni((4 * Hq,), k)
-    for h in range(hops):
+    if mode == 'gap':               # model.py:125-140; linear_v takes the concatenation (model.py:144)
+        for k, ck in enumerate(gap_channels, 1):
+            linear(f'gap{k}.0', ck, Hq, p)
+        Dv = sum(gap_channels)
+    elif mode == 'conv':            # model.py:54: Conv2d(Dv, conv_out, 1); default init bound 1/sqrt(fan_in)
+        b = 1.0 / math.sqrt(Dv)
+        p['visual.1.weight'] = uni((conv_out, Dv, 1, 1), b)
+        p['visual.1.bias'] = uni((conv_out,), b)
+    for h in range(hops if mode == 'attn' else 0):
         pre = f'attention.{h}.'
         linear(pre + 'linear_va', A, Dv, p)
         linear(pre + 'linear_qa', A, Hq, p)
@@ -308,11 +349,11 @@ def trainable_names(p: Dict[str, torch.Tensor]) -> List[str]:
     return [k for k in p if not k.startswith(FROZEN_PREFIXES)]
 
 
-def loss_and_grads(p, feats, tokens, answers, captions=None, hops=1, drop_seeds=None, drop_p=0.5):
+def loss_and_grads(p, feats, tokens, answers, captions=None, hops=1, drop_seeds=None, drop_p=0.5, mode='attn'):
     """One fwd + loss + bwd of the step (train.py:200-203) through autograd."""
     names = trainable_names(p)
     q = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in p.items()}
-    logits = forward(q, feats, tokens, captions, hops, drop_seeds, drop_p)
+    logits = forward(q, feats, tokens, captions, hops, drop_seeds, drop_p, mode=mode)
     loss = cross_entropy(logits, answers)
     grads = torch.autograd.grad(loss, [q[k] for k in names])
     return logits.detach(), loss.detach(), dict(zip(names, grads))
@@ -338,3 +379,10 @@ def synthetic_batch(B: int, R: int, Dv: int, L: int, vq: int, C: int, seed: int,
         cpos = torch.arange(Tc)[None, :]
         out['captions'] = torch.where(cpos < (clen[:, None] - 1), cap, torch.zeros_like(cap))
     return out
+
+
+def synthetic_maps(B: int, channels: Sequence[int], grids: Sequence[int], seed: int, dtype=torch.float32):
+    """Post-ReLU-like NCHW stage maps (B, C_k, g_k, g_k), as ResNet stages feed model.py:161-164."""
+    g = torch.Generator().manual_seed(seed)
+    return [torch.randn((B, c, s, s), generator=g, dtype=torch.float32).clamp_min_(0).to(dtype)
+            for c, s in zip(channels, grids)]

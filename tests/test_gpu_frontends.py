@@ -1,0 +1,171 @@
+"""GPU parity of the two feature-map front-ends (gated multi-scale mean pooling of VQAGAPModel,
+model.py:81-184; 1x1 convolution + channel-major flatten of VQAModel, model.py:29-79) against the CPU
+oracle, and of their kernels against torch on the same inputs.  The oracle's restatement of these two
+classes is not pinned by a reference-generated fixture (model.py cannot be imported: it needs
+torchvision and downloads weights by name): parity unpinned beyond the equations themselves."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import vqa_ref
+
+pytestmark = pytest.mark.gpu
+
+TINY = dict(vq=30, C=11, E=12, Hq=24, Dv=32, A=16, F=16, Hf=8)
+MID = dict(vq=500, C=101, E=44, Hq=200, Dv=256, A=136, F=104, Hf=72)
+
+
+def rel_err(got, ref):
+    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+    return float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('B,C,HW', [(3, 8, 49), (2, 24, 64), (5, 40, 256), (2, 16, 16384), (4, 264, 1024), (1, 8, 7),
+                                    (3, 520, 4096)])
+def test_grid_mean_both_layouts(dtype, B, C, HW):
+    from vqa_amd import _lib
+    from vqa_amd._lib import call, ptr
+    g = torch.Generator().manual_seed(B * 1000 + C + HW)
+    x = torch.randn((B, C, HW), generator=g).clamp_min_(0).to(dtype)
+    ref = x.double().mean(dim=2)
+    tol = 3e-6
+    dt = _lib.dtype_code(dtype)
+    _lib.bind_stream()
+    # (B, C, HW) rows; written at a column offset of a wider buffer
+    xr = x.cuda()
+    out = torch.full((B, C + 16), -1.0, device='cuda')
+    call('vqa_grid_mean', ptr(xr), 0, B, C, HW, ptr(out), C + 16, 8, None, 1, dt)
+    assert rel_err(out[:, 8:8 + C], ref) <= tol
+    assert float(out[:, :8].max()) == -1.0 and float(out[:, 8 + C:].max()) == -1.0
+    # (B, HW, C) channels-last, with and without row splits
+    xc = x.permute(0, 2, 1).contiguous().cuda()
+    for nsp in sorted({1, call('vqa_grid_mean_splits', 1, B, C, HW), 4 if HW >= 64 else 1}):
+        out = torch.full((B, C + 16), -1.0, device='cuda')
+        part = torch.empty(nsp * B * C, device='cuda') if nsp > 1 else None
+        call('vqa_grid_mean', ptr(xc), 1, B, C, HW, ptr(out), C + 16, 8, ptr(part), nsp, dt)
+        assert rel_err(out[:, 8:8 + C], ref) <= tol, nsp
+        assert float(out[:, :8].max()) == -1.0 and float(out[:, 8 + C:].max()) == -1.0
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_flatten_round_trip_is_exact(dtype):
+    from vqa_amd import _lib
+    from vqa_amd._lib import call, ptr
+    B, R, c = 5, 16, 6
+    cp = 8
+    _lib.bind_stream()
+    y = torch.randn((B * R, cp)).to(dtype).cuda()
+    out = torch.zeros((B, c * R), dtype=dtype, device='cuda')
+    call('vqa_flatten_cm', ptr(y), cp, ptr(out), c * R, B, R, c, 0, 0.0, _lib.dtype_code(dtype))
+    ref = y[:, :c].reshape(B, R, c).permute(0, 2, 1).reshape(B, c * R)           # NCHW .view(B, -1)
+    assert torch.equal(out, ref)
+    # dropout mask of the flattened index, as the oracle draws it
+    seed = 12345
+    call('vqa_flatten_cm', ptr(y), cp, ptr(out), c * R, B, R, c, seed, 0.5, _lib.dtype_code(dtype))
+    keep = torch.from_numpy(vqa_ref.dropout_keep_mask(seed, B * c * R, 0.5)).reshape(B, c * R)
+    assert torch.equal(out.float().cpu(), (ref.float().cpu() * 2.0).to(dtype).float() * keep)
+    d = torch.randn((B, c * R), device='cuda')
+    dy = torch.full((B * R, cp), 7.0, dtype=dtype, device='cuda')
+    call('vqa_unflatten_cm', ptr(d), c * R, ptr(dy), cp, B, R, c, _lib.dtype_code(dtype))
+    assert torch.equal(dy[:, :c], d.reshape(B, c, R).permute(0, 2, 1).reshape(B * R, c).to(dtype))
+    assert float(dy[:, c:].abs().max()) == 0.0
+
+
+def _gap_model(kw, channels, dtype):
+    from vqa_amd.model import VQAGAPModel
+    p = vqa_ref.init_params(seed=3, mode='gap', gap_channels=channels, **kw)
+    m = VQAGAPModel(['w'] * kw['vq'], ['a'] * kw['C'], None, dtype=dtype, emb_size=kw['E'], question_out=kw['Hq'],
+                    fusion_in=kw['F'], fusion_hidden=kw['Hf'], gap_channels=channels, seed=1234)
+    m.load_state_dict(p)
+    return m.to('cuda'), p
+
+
+def _check(m, po, vis_ref, vis_gpu, b, mode, dtype, train):
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    seeds = None
+    if train:
+        m.train()
+        seeds = [vqa_ref.site_seed(1234, m.drop_step + 1, s) for s in range(4)]
+    else:
+        m.eval()
+    logits_ref, loss_ref, grads_ref = vqa_ref.loss_and_grads(po, vis_ref, b['tokens'], b['answers'], None, 1,
+                                                             drop_seeds=seeds, mode=mode)
+    to64 = (lambda v: [x.double() for x in v]) if isinstance(vis_ref, list) else (lambda v: v.double())
+    _, _, grads64 = vqa_ref.loss_and_grads({k: v.double() for k, v in po.items()}, to64(vis_ref), b['tokens'],
+                                           b['answers'], None, 1, drop_seeds=seeds, mode=mode)
+    logits = m(vis_gpu, b['tokens'].cuda())
+    assert rel_err(logits, logits_ref) <= tol
+    loss = torch.nn.functional.cross_entropy(logits.float(), b['answers'].cuda())
+    m.zero_grad()
+    loss.backward()
+    assert abs(float(loss.detach()) - float(loss_ref)) <= tol * max(1.0, abs(float(loss_ref)))
+    named = dict(m.named_parameters())
+    for k, gref in grads_ref.items():
+        assert named[k].grad is not None, k
+        noise = rel_err(gref, grads64[k])
+        assert rel_err(named[k].grad, grads64[k]) <= max(2 * tol, 4 * noise), (k, rel_err(named[k].grad, grads64[k]), noise)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('kw,channels,grids,B', [(TINY, (8, 16, 24, 32), (8, 4, 4, 2), 4),
+                                                 (MID, (32, 64, 128, 256), (32, 16, 8, 4), 19)])
+@pytest.mark.parametrize('channels_last', [False, True])
+def test_gap_model_forward_backward(dtype, kw, channels, grids, B, channels_last):
+    m, p = _gap_model(kw, channels, dtype)
+    maps = [x.to(dtype) for x in vqa_ref.synthetic_maps(B, channels, grids, seed=9)]
+    b = vqa_ref.synthetic_batch(B, 4, 8, 14, kw['vq'], kw['C'], seed=5)
+    po = p if dtype == torch.float32 else {k: v.to(torch.bfloat16).float() for k, v in p.items()}
+    gpu_maps = [x.cuda() for x in maps]
+    if channels_last:
+        gpu_maps = [x.contiguous(memory_format=torch.channels_last) for x in gpu_maps]
+    ref_maps = [x.float() for x in maps]
+    _check(m, po, ref_maps, gpu_maps, b, 'gap', dtype, train=False)
+    _check(m, po, ref_maps, gpu_maps, b, 'gap', dtype, train=True)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('kw,input_size,B', [(TINY, 128, 4), (MID, 256, 21), (MID, 128, 8)])
+def test_conv_model_forward_backward(dtype, kw, input_size, B):
+    from vqa_amd.model import VQAModel
+    g = input_size // 32
+    R = g * g
+    c_out = kw['Dv'] // R
+    Cin = 64
+    p = vqa_ref.init_params(seed=3, mode='conv', conv_out=c_out, **{**kw, 'Dv': Cin})
+    # linear_v takes the flattened conv output (VISUAL_OUT = c_out * R = kw['Dv'])
+    p['linear_v.weight'] = vqa_ref.init_params(seed=4, **kw)['linear_v.weight']
+    m = VQAModel(['w'] * kw['vq'], ['a'] * kw['C'], None, input_size, dtype=dtype, emb_size=kw['E'],
+                 question_out=kw['Hq'], visual_out=kw['Dv'], fusion_in=kw['F'], fusion_hidden=kw['Hf'],
+                 map_channels=Cin, seed=1234)
+    m.load_state_dict(p)
+    m = m.to('cuda')
+    fmap = vqa_ref.synthetic_maps(B, (Cin,), (g,), seed=11)[0].to(dtype)
+    b = vqa_ref.synthetic_batch(B, 4, 8, 14, kw['vq'], kw['C'], seed=6)
+    po = p if dtype == torch.float32 else {k: v.to(torch.bfloat16).float() for k, v in p.items()}
+    _check(m, po, fmap.float(), fmap.cuda(), b, 'conv', dtype, train=False)
+    _check(m, po, fmap.float(), fmap.cuda(), b, 'conv', dtype, train=True)
+
+
+def test_gap_train_step_matches_oracle_adam():
+    """Three fused steps of the gated-pooling model against the oracle's autograd + Adam."""
+    kw, channels, grids = MID, (32, 64, 128, 256), (16, 8, 4, 2)
+    m, p = _gap_model(kw, channels, torch.float32)
+    m.train()
+    po = {k: v.clone() for k, v in p.items()}
+    names = vqa_ref.trainable_names(po)
+    mom = {k: torch.zeros_like(po[k]) for k in names}
+    var = {k: torch.zeros_like(po[k]) for k in names}
+    lr = 1e-3
+    for step in range(1, 4):
+        maps = vqa_ref.synthetic_maps(24, channels, grids, seed=50 + step)
+        b = vqa_ref.synthetic_batch(24, 4, 8, 14, kw['vq'], kw['C'], seed=100 + step)
+        seeds = [vqa_ref.site_seed(1234, step, s) for s in range(4)]
+        _, loss_ref, grads = vqa_ref.loss_and_grads(po, maps, b['tokens'], b['answers'], None, 1, drop_seeds=seeds, mode='gap')
+        for k in names:
+            vqa_ref.adam_step(po[k], grads[k], mom[k], var[k], step, lr)
+        loss = m.train_step([x.cuda() for x in maps], b['tokens'].cuda(), b['answers'].cuda(), lr=lr)
+        assert abs(float(loss) - float(loss_ref)) <= 1e-5 * max(1.0, abs(float(loss_ref)))
+    sd = m.state_dict()
+    for k in names:
+        assert rel_err(sd[k], po[k]) <= 2e-5, k

@@ -26,6 +26,12 @@ _SIGNATURES = {
     'vqa_lstm_cell': [_p, _i, _z, _p, _i, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     'vqa_caption_pool': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     'vqa_inv_norm': [_p, _p, _l, _i, _i, _i, _p],
+    'vqa_grid_mean_splits': [_i, _i, _i, _i],
+    'vqa_grid_mean': [_p, _i, _i, _i, _i, _p, _i, _i, _p, _i, _i, _p],
+    'vqa_gate_fwd': [_p, _i, _z, _p, _p, _i, _p, _i, _p, _i, _i, _i, _u, _f, _i, _p],
+    'vqa_gate_bwd': [_p, _i, _p, _i, _p, _i, _p, _i, _i, _i, _i, _p],
+    'vqa_flatten_cm': [_p, _i, _p, _i, _i, _i, _i, _u, _f, _i, _p],
+    'vqa_unflatten_cm': [_p, _i, _p, _i, _i, _i, _i, _i, _p],
     'vqa_attn_lds_bytes': [_i, _i, _i],
     'vqa_attn_fwd': [_p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     'vqa_attn_bwd': [_p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _i, _p, _i, _p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _p],
@@ -45,7 +51,8 @@ _SIGNATURES = {
     'vqa_adam_step': [_p, _p, _p, _p, _p, _l, _f, _f, _f, _f, _i, _f, _p],
 }
 _RESTYPE = {'vqa_last_error_string': C.c_char_p, 'vqa_attn_lds_bytes': C.c_size_t}
-_NO_STATUS = {'vqa_version', 'vqa_last_error_string', 'vqa_attn_lds_bytes', 'vqa_gemm_splitk_hint'}
+_NO_STATUS = {'vqa_version', 'vqa_last_error_string', 'vqa_attn_lds_bytes', 'vqa_gemm_splitk_hint',
+              'vqa_grid_mean_splits'}
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

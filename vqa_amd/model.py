@@ -95,7 +95,11 @@ class _VQAFunction(torch.autograd.Function):
         return (None, None, None, None, *grads)
 
 
-class VQAAttnModel(nn.Module):
+class _VQAHeadModel(nn.Module):
+    """Question encoder + fusion head + classifier + loss / optimiser shared by the three model
+    classes; a subclass supplies the visual front-end that turns its image input into the
+    (B, Dv) vector entering ``linear_v`` (hooks ``_build_visual`` ... ``_visual_backward``)."""
+
     def __init__(self, vocab_questions: Sequence[str], vocab_answers: Sequence[str], args=None,
                  input_size: int = 512, *, dtype: torch.dtype = torch.bfloat16, emb_size: int = 620,
                  question_out: int = QUESTION_OUT, visual_out: int = VISUAL_OUT,
@@ -127,7 +131,7 @@ class VQAAttnModel(nn.Module):
         self.seq2vec = _Seq2Vec(len(vocab_questions), emb_size, question_out, gen)
         for p in self.seq2vec.parameters():          # frozen, as model.py:42-43
             p.requires_grad = False
-        self.attention = nn.ModuleList([_Hop(self.Dv, self.Hq, self.A, k + 1 < hops) for k in range(hops)])
+        self._build_visual(gen)
         self.linear_q = nn.Linear(self.Hq, self.F)
         self.linear_v = nn.Linear(self.Dv, self.F)
         self.linear_classif1 = nn.Linear(self.F + self.Ec, self.Hf)
@@ -166,18 +170,7 @@ class VQAAttnModel(nn.Module):
                ('linear_classif1.weight', self.linear_classif1.weight), ('linear_classif1.bias', self.linear_classif1.bias),
                ('linear_v.weight', self.linear_v.weight), ('linear_v.bias', self.linear_v.bias),
                ('linear_q.weight', self.linear_q.weight), ('linear_q.bias', self.linear_q.bias)]
-        for k in reversed(range(self.hops)):
-            hop = self.attention[k]
-            pre = f'attention.{k}.'
-            out += [(pre + 'linear_a.weight', hop.linear_a.weight), (pre + 'linear_a.bias', hop.linear_a.bias),
-                    (pre + 'linear_qa.weight', hop.linear_qa.weight), (pre + 'linear_qa.bias', hop.linear_qa.bias),
-                    (pre + 'linear_va.bias', hop.linear_va.bias)]
-            if k > 0:
-                prev = self.attention[k - 1]
-                ppre = f'attention.{k - 1}.'
-                out += [(ppre + 'linear_u.weight', prev.linear_u.weight), (ppre + 'linear_u.bias', prev.linear_u.bias)]
-            out += [(pre + 'linear_va.weight', hop.linear_va.weight)]
-        return out
+        return out + self._visual_trainable_order()
 
     def _materialize(self, device: torch.device):
         """Move trainable parameters into one flat fp32 buffer (parameters become
@@ -211,10 +204,7 @@ class VQAAttnModel(nn.Module):
         self._shadow_version = -1
         # bucket boundaries (element ranges of the flat buffer) in completion order
         names = [n for n, _ in order]
-        cuts = [names.index('linear_v.weight')]
-        for k in reversed(range(self.hops)):
-            cuts += [names.index(f'attention.{k}.linear_a.weight'), names.index(f'attention.{k}.linear_va.weight')]
-        cuts = sorted(set(cuts))
+        cuts = sorted({names.index(n) for n in ['linear_v.weight'] + self._visual_bucket_starts()})
         starts = [0] + [offsets[c][0] for c in cuts]
         ends = starts[1:] + [total]
         self.buckets = [(s, e) for s, e in zip(starts, ends) if e > s]
@@ -279,8 +269,9 @@ class VQAAttnModel(nn.Module):
         self._frozen_key = key
 
     # ------------------------------------------------------------------ workspace
-    def _workspace(self, B: int, R: int, L: int, Tc: int, device) -> Dict[str, torch.Tensor]:
-        key = (B, R, L, Tc, str(device))
+    def _workspace(self, B: int, geom, L: int, Tc: int, device) -> Dict[str, torch.Tensor]:
+        """Per-shape buffers; `geom` is the front-end's geometry (region count / grid sizes)."""
+        key = (B, geom, L, Tc, str(device))
         ws = self._ws.get(key)
         if ws is not None:
             return ws
@@ -294,25 +285,15 @@ class VQAAttnModel(nn.Module):
         ws = {
             'len': z((B,), torch.int32), 'x_emb': z((L * B, Ep), tdt), 'xg': z((L * B, 4 * H), tdt),
             'c': z((B, H), f32), 'h': z((B, H), tdt), 'q32': z((B, H), f32), 'qT': z((B, H), tdt),
-            'inv_norm': z((B * R,), f32),
             'pooled_d': z((B, Dv), tdt), 'q_d': z((B, H), tdt),
             'xv': z((B, F), f32), 'xq': z((B, F), f32), 'x': z((B, F + Ec), tdt),
             'h1t': z((B, Hf), f32), 'h1d': z((B, Hf), tdt), 'logits': z((B, Cp), f32),
             'loss_rows': z((B,), f32), 'loss': z((1,), f32), 'dlogits': z((B, Cp), tdt),
             'dz1': z((B, Hf), tdt), 'dzv': z((B, F), tdt), 'dzq': z((B, F), tdt),
-            'd_pooled': z((B, Dv), f32), 'dP': z((B * R, A), tdt),
-            'dqa32': z((B, A), f32), 'dqaT': z((B, A), tdt), 'dwa_part': z((B, A), f32), 'dc_part': z((B,), f32),
-            'du32': z((B, H), f32), 'duT': z((B, H), tdt),
+            'd_pooled': z((B, Dv), f32),
             'pred': z((B,), torch.int64),
         }
-        for k in range(self.hops):
-            ws[f'P{k}'] = z((B * R, A), tdt)
-            ws[f'qa{k}'] = z((B, A), f32)
-            ws[f'p{k}'] = z((B, R), f32)
-            ws[f'pooled{k}'] = z((B, Dv), tdt)
-            if k > 0:
-                ws[f'u32_{k}'] = z((B, H), f32)
-                ws[f'uT_{k}'] = z((B, H), tdt)
+        self._visual_workspace(ws, z, B, geom)
         self._ws[key] = ws
         return ws
 
@@ -361,19 +342,14 @@ class VQAAttnModel(nn.Module):
 
     # ------------------------------------------------------------------ forward
     def _prepare_inputs(self, input_v, input_q, captions):
-        dev = input_q.device if isinstance(input_q, torch.Tensor) and input_q.is_cuda else input_v.device
+        dev = input_q.device
         if dev.type != 'cuda':
-            raise _lib.VqaHipError('VQAAttnModel runs on a HIP device only (inputs must be cuda tensors); '
+            raise _lib.VqaHipError(f'{type(self).__name__} runs on a HIP device only (inputs must be cuda tensors); '
                                    'there is no CPU path')
-        if input_v.dim() == 4:                       # (B, Dv, H, W) as model.py:159 produces
-            B, Dv, Hh, Ww = input_v.shape
-            input_v = input_v.permute(0, 2, 3, 1).reshape(B, Hh * Ww, Dv)
-        if input_v.dim() != 3 or input_v.shape[2] != self.Dv:
-            raise ValueError(f'image_feats must be (B, R, {self.Dv}) or (B, {self.Dv}, H, W)')
-        feats = input_v.to(self.compute_dtype).contiguous()
+        feats, nb = self._prepare_visual(input_v)
         tokens = input_q.long().contiguous()
-        if tokens.dim() != 2 or tokens.shape[0] != feats.shape[0]:
-            raise ValueError('question_tokens must be (B, L) with the batch of image_feats')
+        if tokens.dim() != 2 or tokens.shape[0] != nb:
+            raise ValueError('question_tokens must be (B, L) with the batch of the image input')
         if self.Ec:
             if captions is None:
                 raise ValueError('this model was built with a caption stream: pass captions (B, Tc) int64')
@@ -384,7 +360,7 @@ class VQAAttnModel(nn.Module):
 
     def forward(self, input_v, input_q, captions=None):
         feats, tokens, captions = self._prepare_inputs(input_v, input_q, captions)
-        self._materialize(feats.device)
+        self._materialize(tokens.device)
         params = [p for _, p in self._trainable_order()]
         if torch.is_grad_enabled() and any(p.requires_grad for p in params):
             return _VQAFunction.apply(self, feats, tokens, captions, *params)
@@ -423,40 +399,23 @@ class VQAAttnModel(nn.Module):
         return ws['q32']
 
     def _forward_impl(self, feats, tokens, captions):
-        B, R, Dv = feats.shape
-        L = tokens.shape[1]
-        dev = feats.device
+        B, L = tokens.shape
+        dev = tokens.device
         Tc = captions.shape[1] if captions is not None else 0
         _lib.bind_stream()
         self._materialize(dev)
-        ws = self._workspace(B, R, L, Tc, dev)
-        H, A, F, Hf, Ec, C, Cp, dt = self.Hq, self.A, self.F, self.Hf, self.Ec, self.num_classes, _pad8(self.num_classes), self.dt
+        ws = self._workspace(B, self._geometry(feats), L, Tc, dev)
+        H, F, Hf, Ec, C, Cp, dt = self.Hq, self.F, self.Hf, self.Ec, self.num_classes, _pad8(self.num_classes), self.dt
+        Dv = self.Dv
         seeds, p = self._drop_seeds()
 
         # parameter-independent prologue first: a gradient bucket still being all-reduced from the
         # previous train_step (and its Adam update) is only needed from here on
         self.encode_question(tokens, ws)
-        call('vqa_inv_norm', ptr(feats), ptr(ws['inv_norm']), B * R, Dv, Dv, dt)
+        self._visual_prologue(ws, feats, B)
         self._finish_pending()
         self._refresh_shadow()
-        u32, uT = ws['q32'], ws['qT']
-        for k in range(self.hops):
-            pre = f'attention.{k}.'
-            call('vqa_gemm_fused', ptr(feats), Dv, 1, ptr(self._w(pre + 'linear_va.weight')), Dv, 1, ptr(ws[f'P{k}']), A,
-                 B * R, A, Dv, ptr(self._f32(pre + 'linear_va.bias')), ptr(ws['inv_norm']), 0, dt, dt, self.gemm_engine)
-            self._linear(uT, H, pre + 'linear_qa.weight', pre + 'linear_qa.bias', B, A, H, out_pre=ws[f'qa{k}'], ld_pre=A)
-            ev = self._event_pair('attn_fwd')
-            call('vqa_attn_fwd', ptr(ws[f'P{k}']), A, ptr(feats), Dv, ptr(ws[f'qa{k}']), A,
-                 ptr(self._f32(pre + 'linear_a.weight')), ptr(self._f32(pre + 'linear_a.bias')), ptr(ws['inv_norm']),
-                 ptr(ws[f'p{k}']), ptr(ws[f'pooled{k}']), None, Dv, B, R, A, Dv, dt)
-            if ev is not None:
-                ev[1].record()
-            if k + 1 < self.hops:
-                self._linear(ws[f'pooled{k}'], Dv, pre + 'linear_u.weight', pre + 'linear_u.bias', B, H, Dv,
-                             addend=u32, ld_add=H, out_pre=ws[f'u32_{k + 1}'], ld_pre=H, out_post=ws[f'uT_{k + 1}'], ld_post=H)
-                u32, uT = ws[f'u32_{k + 1}'], ws[f'uT_{k + 1}']
-        pooled = ws[f'pooled{self.hops - 1}']
-        call('vqa_dropout', ptr(pooled), Dv, ptr(ws['pooled_d']), Dv, B, Dv, seeds[0], p, dt)
+        self._visual_forward(ws, feats, B, seeds[0], p)           # -> ws['pooled_d'] = dropout(visual vector)
         call('vqa_dropout', ptr(ws['qT']), H, ptr(ws['q_d']), H, B, H, seeds[1], p, dt)
         self._linear(ws['pooled_d'], Dv, 'linear_v.weight', 'linear_v.bias', B, F, Dv, act=1, out_pre=ws['xv'], ld_pre=F)
         self._linear(ws['q_d'], H, 'linear_q.weight', 'linear_q.bias', B, F, H, act=1, out_pre=ws['xq'], ld_pre=F)
@@ -468,13 +427,13 @@ class VQAAttnModel(nn.Module):
                      out_pre=ws['h1t'], ld_pre=Hf, out_post=ws['h1d'], ld_post=Hf, seed=seeds[3], p=p)
         self._linear(ws['h1d'], Hf, 'linear_classif2.weight', 'linear_classif2.bias', B, C, Hf,
                      out_pre=ws['logits'], ld_pre=Cp)
-        self._ctx = (ws, feats, B, R, L, seeds, p)
+        self._ctx = (ws, feats, B, L, seeds, p)
         return ws['logits'][:, :C]
 
     # ------------------------------------------------------------------ backward
     def _backward_from_dense(self, dlogits: torch.Tensor):
         """Backward from an arbitrary d loss / d logits (B, C) tensor (autograd path)."""
-        ws, feats, B, R, L, seeds, p = self._ctx
+        ws, feats, B, L, seeds, p = self._ctx
         C, Cp = self.num_classes, _pad8(self.num_classes)
         d = dlogits.to(torch.float32).contiguous()
         _lib.bind_stream()
@@ -483,8 +442,8 @@ class VQAAttnModel(nn.Module):
 
     def _backward_impl(self):
         """Gradients of every trainable parameter from ws['dlogits'] into the flat gradient buffer."""
-        ws, feats, B, R, L, seeds, p = self._ctx
-        H, A, Dv, F, Hf, Ec, C, Cp, dt = self.Hq, self.A, self.Dv, self.F, self.Hf, self.Ec, self.num_classes, _pad8(self.num_classes), self.dt
+        ws, feats, B, L, seeds, p = self._ctx
+        H, Dv, F, Hf, Ec, C, Cp, dt = self.Hq, self.Dv, self.F, self.Hf, self.Ec, self.num_classes, _pad8(self.num_classes), self.dt
         _lib.bind_stream()
         g = self._g
         # classifier
@@ -507,41 +466,13 @@ class VQAAttnModel(nn.Module):
         slab, sk, st = self._gemm_slabs(ws['dzv'], F, 1, self._w('linear_v.weight'), Dv, 0, B, Dv, F)
         call('vqa_epilogue', ptr(slab), sk, st, B, Dv, None, None, None, 0, 0, None, 0, ptr(ws['d_pooled']), Dv,
              _lib.F32, seeds[0], p)
-        # attention hops, last to first
-        du_carry = None
-        for k in reversed(range(self.hops)):
-            pre = f'attention.{k}.'
-            uT = ws['qT'] if k == 0 else ws[f'uT_{k}']
-            call('vqa_attn_bwd', ptr(ws[f'P{k}']), A, ptr(feats), Dv, ptr(ws[f'qa{k}']), A,
-                 ptr(self._f32(pre + 'linear_a.weight')), ptr(ws['inv_norm']), ptr(ws[f'p{k}']), ptr(ws['d_pooled']), Dv,
-                 ptr(ws['dP']), A, ptr(ws['dqa32']), ptr(ws['dqaT']), A, ptr(ws['dwa_part']), ptr(ws['dc_part']),
-                 B, R, A, Dv, dt)
-            call('vqa_colsum', ptr(ws['dwa_part']), A, ptr(g(pre + 'linear_a.weight')), B, A, _lib.F32)
-            call('vqa_sum_scale', ptr(ws['dc_part']), ptr(g(pre + 'linear_a.bias')), B, 1.0)
-            call('vqa_colsum', ptr(ws['dqa32']), A, ptr(g(pre + 'linear_qa.bias')), B, A, _lib.F32)
-            call('vqa_colsum', ptr(ws['dqa32']), A, ptr(g(pre + 'linear_va.bias')), B, A, _lib.F32)
-            self._wgrad(ws['dqaT'], A, uT, H, pre + 'linear_qa.weight', A, H, B)
-            if k > 0:
-                ppre = f'attention.{k - 1}.'
-                slab, sk, st = self._gemm_slabs(ws['dqaT'], A, 1, self._w(pre + 'linear_qa.weight'), H, 0, B, H, A)
-                call('vqa_epilogue', ptr(slab), sk, st, B, H, None, None, ptr(du_carry), H, 0, ptr(ws['du32']), H,
-                     ptr(ws['duT']), H, dt, 0, 0.0)
-                du_carry = ws['du32']
-                self._wgrad(ws['duT'], H, ws[f'pooled{k - 1}'], Dv, ppre + 'linear_u.weight', H, Dv, B)
-                call('vqa_colsum', ptr(ws['du32']), H, ptr(g(ppre + 'linear_u.bias')), B, H, _lib.F32)
-            self._bucket_done(pre + 'linear_va.bias')
-            self._wgrad(ws['dP'], A, feats, Dv, pre + 'linear_va.weight', A, Dv, B * R)
-            self._bucket_done(pre + 'linear_va.weight')
-            if k > 0:
-                slab, sk, st = self._gemm_slabs(ws['duT'], H, 1, self._w(ppre + 'linear_u.weight'), Dv, 0, B, Dv, H)
-                call('vqa_epilogue', ptr(slab), sk, st, B, Dv, None, None, None, 0, 0, ptr(ws['d_pooled']), Dv,
-                     None, 0, _lib.F32, 0, 0.0)
+        self._visual_backward(ws, feats, B)
 
     # ------------------------------------------------------------------ loss / prediction / step
     def loss_and_grad_logits(self, answers: torch.Tensor) -> torch.Tensor:
         """Fused softmax cross-entropy (mean) of the last forward + its gradient into the
         backward workspace.  Returns the 1-element device tensor holding the loss."""
-        ws, feats, B, R, L, seeds, p = self._ctx
+        ws, feats, B, L, seeds, p = self._ctx
         C, Cp = self.num_classes, _pad8(self.num_classes)
         ans = answers.long().contiguous()
         _lib.bind_stream()
@@ -553,7 +484,7 @@ class VQAAttnModel(nn.Module):
     def predict(self, logits: Optional[torch.Tensor] = None, answers=None, type_ids=None, counters=None, n_types: int = 4):
         """First-max argmax of the last forward's logits (train.py:106); optionally
         accumulates per-question-type count / right counters on the device."""
-        ws, feats, B, R, L, seeds, p = self._ctx
+        ws, feats, B, L, seeds, p = self._ctx
         C, Cp = self.num_classes, _pad8(self.num_classes)
         _lib.bind_stream()
         call('vqa_argmax_accuracy', ptr(ws['logits']), Cp, B, C, ptr(answers), ptr(type_ids), n_types, ptr(ws['pred']),
@@ -602,7 +533,7 @@ class VQAAttnModel(nn.Module):
         gradient bucket are completed inside the next call (after its question-encoder / inv-norm
         prologue, which they do not affect) or by sync(); results are identical either way."""
         feats, tokens, captions = self._prepare_inputs(input_v, input_q, captions)
-        self._materialize(feats.device)
+        self._materialize(tokens.device)
         betas, eps = (0.9, 0.999), 1e-8
         with torch.no_grad():
             self._forward_impl(feats, tokens, captions)
@@ -647,3 +578,287 @@ class VQAAttnModel(nn.Module):
         self._shadow_fresh = False
         self._frozen_key = None
         return out
+
+
+class VQAAttnModel(_VQAHeadModel):
+    """Question-conditioned attention over precomputed region features (B, R, Dv) (or the
+    (B, Dv, H, W) map model.py:159 produces): K hops of tanh-add attention + softmax over the grid +
+    weighted pooling replace the reference's unweighted mean (model.py:161-164)."""
+
+    def _build_visual(self, gen):
+        self.attention = nn.ModuleList([_Hop(self.Dv, self.Hq, self.A, k + 1 < self.hops) for k in range(self.hops)])
+
+    def _visual_trainable_order(self):
+        out = []
+        for k in reversed(range(self.hops)):
+            hop = self.attention[k]
+            pre = f'attention.{k}.'
+            out += [(pre + 'linear_a.weight', hop.linear_a.weight), (pre + 'linear_a.bias', hop.linear_a.bias),
+                    (pre + 'linear_qa.weight', hop.linear_qa.weight), (pre + 'linear_qa.bias', hop.linear_qa.bias),
+                    (pre + 'linear_va.bias', hop.linear_va.bias)]
+            if k > 0:
+                prev = self.attention[k - 1]
+                ppre = f'attention.{k - 1}.'
+                out += [(ppre + 'linear_u.weight', prev.linear_u.weight), (ppre + 'linear_u.bias', prev.linear_u.bias)]
+            out += [(pre + 'linear_va.weight', hop.linear_va.weight)]
+        return out
+
+    def _visual_bucket_starts(self):
+        out = []
+        for k in range(self.hops):
+            out += [f'attention.{k}.linear_a.weight', f'attention.{k}.linear_va.weight']
+        return out
+
+    def _prepare_visual(self, input_v):
+        if input_v.dim() == 4:                       # (B, Dv, H, W) as model.py:159 produces
+            B, Dv, Hh, Ww = input_v.shape
+            input_v = input_v.permute(0, 2, 3, 1).reshape(B, Hh * Ww, Dv)
+        if input_v.dim() != 3 or input_v.shape[2] != self.Dv:
+            raise ValueError(f'image_feats must be (B, R, {self.Dv}) or (B, {self.Dv}, H, W)')
+        feats = input_v.to(self.compute_dtype).contiguous()
+        return feats, feats.shape[0]
+
+    def _geometry(self, feats):
+        return feats.shape[1]
+
+    def _visual_workspace(self, ws, z, B, R):
+        tdt, f32 = self.compute_dtype, torch.float32
+        H, A, Dv = self.Hq, self.A, self.Dv
+        ws.update({'inv_norm': z((B * R,), f32), 'dP': z((B * R, A), tdt),
+                   'dqa32': z((B, A), f32), 'dqaT': z((B, A), tdt), 'dwa_part': z((B, A), f32), 'dc_part': z((B,), f32),
+                   'du32': z((B, H), f32), 'duT': z((B, H), tdt)})
+        for k in range(self.hops):
+            ws[f'P{k}'] = z((B * R, A), tdt)
+            ws[f'qa{k}'] = z((B, A), f32)
+            ws[f'p{k}'] = z((B, R), f32)
+            ws[f'pooled{k}'] = z((B, Dv), tdt)
+            if k > 0:
+                ws[f'u32_{k}'] = z((B, H), f32)
+                ws[f'uT_{k}'] = z((B, H), tdt)
+
+    def _visual_prologue(self, ws, feats, B):
+        R, Dv = feats.shape[1], self.Dv
+        call('vqa_inv_norm', ptr(feats), ptr(ws['inv_norm']), B * R, Dv, Dv, self.dt)
+
+    def _visual_forward(self, ws, feats, B, seed, p):
+        R = feats.shape[1]
+        H, A, Dv, dt = self.Hq, self.A, self.Dv, self.dt
+        u32, uT = ws['q32'], ws['qT']
+        for k in range(self.hops):
+            pre = f'attention.{k}.'
+            call('vqa_gemm_fused', ptr(feats), Dv, 1, ptr(self._w(pre + 'linear_va.weight')), Dv, 1, ptr(ws[f'P{k}']), A,
+                 B * R, A, Dv, ptr(self._f32(pre + 'linear_va.bias')), ptr(ws['inv_norm']), 0, dt, dt, self.gemm_engine)
+            self._linear(uT, H, pre + 'linear_qa.weight', pre + 'linear_qa.bias', B, A, H, out_pre=ws[f'qa{k}'], ld_pre=A)
+            ev = self._event_pair('attn_fwd')
+            call('vqa_attn_fwd', ptr(ws[f'P{k}']), A, ptr(feats), Dv, ptr(ws[f'qa{k}']), A,
+                 ptr(self._f32(pre + 'linear_a.weight')), ptr(self._f32(pre + 'linear_a.bias')), ptr(ws['inv_norm']),
+                 ptr(ws[f'p{k}']), ptr(ws[f'pooled{k}']), None, Dv, B, R, A, Dv, dt)
+            if ev is not None:
+                ev[1].record()
+            if k + 1 < self.hops:
+                self._linear(ws[f'pooled{k}'], Dv, pre + 'linear_u.weight', pre + 'linear_u.bias', B, H, Dv,
+                             addend=u32, ld_add=H, out_pre=ws[f'u32_{k + 1}'], ld_pre=H, out_post=ws[f'uT_{k + 1}'], ld_post=H)
+                u32, uT = ws[f'u32_{k + 1}'], ws[f'uT_{k + 1}']
+        pooled = ws[f'pooled{self.hops - 1}']
+        call('vqa_dropout', ptr(pooled), Dv, ptr(ws['pooled_d']), Dv, B, Dv, seed, p, dt)
+
+    def _visual_backward(self, ws, feats, B):
+        R = feats.shape[1]
+        H, A, Dv, dt = self.Hq, self.A, self.Dv, self.dt
+        g = self._g
+        # attention hops, last to first
+        du_carry = None
+        for k in reversed(range(self.hops)):
+            pre = f'attention.{k}.'
+            uT = ws['qT'] if k == 0 else ws[f'uT_{k}']
+            call('vqa_attn_bwd', ptr(ws[f'P{k}']), A, ptr(feats), Dv, ptr(ws[f'qa{k}']), A,
+                 ptr(self._f32(pre + 'linear_a.weight')), ptr(ws['inv_norm']), ptr(ws[f'p{k}']), ptr(ws['d_pooled']), Dv,
+                 ptr(ws['dP']), A, ptr(ws['dqa32']), ptr(ws['dqaT']), A, ptr(ws['dwa_part']), ptr(ws['dc_part']),
+                 B, R, A, Dv, dt)
+            call('vqa_colsum', ptr(ws['dwa_part']), A, ptr(g(pre + 'linear_a.weight')), B, A, _lib.F32)
+            call('vqa_sum_scale', ptr(ws['dc_part']), ptr(g(pre + 'linear_a.bias')), B, 1.0)
+            call('vqa_colsum', ptr(ws['dqa32']), A, ptr(g(pre + 'linear_qa.bias')), B, A, _lib.F32)
+            call('vqa_colsum', ptr(ws['dqa32']), A, ptr(g(pre + 'linear_va.bias')), B, A, _lib.F32)
+            self._wgrad(ws['dqaT'], A, uT, H, pre + 'linear_qa.weight', A, H, B)
+            if k > 0:
+                ppre = f'attention.{k - 1}.'
+                slab, sk, st = self._gemm_slabs(ws['dqaT'], A, 1, self._w(pre + 'linear_qa.weight'), H, 0, B, H, A)
+                call('vqa_epilogue', ptr(slab), sk, st, B, H, None, None, ptr(du_carry), H, 0, ptr(ws['du32']), H,
+                     ptr(ws['duT']), H, dt, 0, 0.0)
+                du_carry = ws['du32']
+                self._wgrad(ws['duT'], H, ws[f'pooled{k - 1}'], Dv, ppre + 'linear_u.weight', H, Dv, B)
+                call('vqa_colsum', ptr(ws['du32']), H, ptr(g(ppre + 'linear_u.bias')), B, H, _lib.F32)
+            self._bucket_done(pre + 'linear_va.bias')
+            self._wgrad(ws['dP'], A, feats, Dv, pre + 'linear_va.weight', A, Dv, B * R)
+            self._bucket_done(pre + 'linear_va.weight')
+            if k > 0:
+                slab, sk, st = self._gemm_slabs(ws['duT'], H, 1, self._w(ppre + 'linear_u.weight'), Dv, 0, B, Dv, H)
+                call('vqa_epilogue', ptr(slab), sk, st, B, Dv, None, None, None, 0, 0, ptr(ws['d_pooled']), Dv,
+                     None, 0, _lib.F32, 0, 0.0)
+
+
+class VQAGAPModel(_VQAHeadModel):
+    """The reference's VQAGAPModel (model.py:81-184) on precomputed ResNet stage maps: per stage
+    the mean over the grid times a question gate ``gapK = Sigmoid(Linear(QUESTION_OUT, C_k))``,
+    concatenated into the VISUAL_OUT_GAP = 3840-wide vector entering ``linear_v``.  The frozen
+    ResNet-152 itself (model.py:98-118, 156-159) is outside this module: ``input_v`` is the list of
+    its four stage outputs, each (B, C_k, H_k, W_k) in NCHW or channels_last memory format."""
+
+    def __init__(self, vocab_questions, vocab_answers, args=None, input_size: int = 512, *,
+                 gap_channels: Sequence[int] = (256, 512, 1024, 2048), **kw):
+        self.gap_channels = tuple(int(c) for c in gap_channels)
+        for c in self.gap_channels:
+            if c % 8:
+                raise ValueError('stage channel counts must be multiples of 8')
+        kw['visual_out'] = sum(self.gap_channels)          # VISUAL_OUT_GAP (model.py:144)
+        super().__init__(vocab_questions, vocab_answers, args, input_size, **kw)
+
+    def _build_visual(self, gen):
+        for k, c in enumerate(self.gap_channels, 1):        # names as model.py:125-140
+            setattr(self, f'gap{k}', nn.Sequential(nn.Linear(self.Hq, c), nn.Sigmoid()))
+
+    def _gates(self):
+        return [getattr(self, f'gap{k}')[0] for k in range(1, len(self.gap_channels) + 1)]
+
+    def _visual_trainable_order(self):
+        # the gate weights (and the biases) sit back to back in the flat buffer, so that the
+        # gates of all stages are one (sum C_k) x Hq product
+        gs = self._gates()
+        return ([(f'gap{k}.0.bias', g.bias) for k, g in enumerate(gs, 1)] +
+                [(f'gap{k}.0.weight', g.weight) for k, g in enumerate(gs, 1)])
+
+    def _visual_bucket_starts(self):
+        return ['gap1.0.bias']
+
+    def _prepare_visual(self, input_v):
+        if not isinstance(input_v, (list, tuple)) or len(input_v) != len(self.gap_channels):
+            raise ValueError(f'input_v must be the list of {len(self.gap_channels)} stage maps (B, C_k, H_k, W_k)')
+        maps = []
+        for m, c in zip(input_v, self.gap_channels):
+            if m.dim() != 4 or m.shape[1] != c or m.shape[0] != input_v[0].shape[0]:
+                raise ValueError(f'stage map must be (B, {c}, H, W), got {tuple(m.shape)}')
+            m = m.to(self.compute_dtype)
+            if m.is_contiguous():
+                layout = 0
+            elif m.is_contiguous(memory_format=torch.channels_last):
+                layout = 1
+            else:
+                m, layout = m.contiguous(), 0
+            maps.append((m, layout))
+        return tuple(maps), input_v[0].shape[0]
+
+    def _geometry(self, maps):
+        return tuple((m.shape[2] * m.shape[3], layout) for m, layout in maps)
+
+    def _visual_workspace(self, ws, z, B, geom):
+        f32 = torch.float32
+        Dv = self.Dv
+        ws.update({'gmean': z((B, Dv), f32), 'gate': z((B, Dv), f32), 'dzg': z((B, Dv), self.compute_dtype)})
+        nsp = [call('vqa_grid_mean_splits', layout, B, c, hw) for (hw, layout), c in zip(geom, self.gap_channels)]
+        ws['gm_splits'] = nsp
+        need = max([n * B * c for n, c in zip(nsp, self.gap_channels) if n > 1], default=0)
+        ws['gm_part'] = z((need,), f32) if need else None
+
+    def _visual_prologue(self, ws, maps, B):
+        col = 0
+        for (m, layout), c, nsp in zip(maps, self.gap_channels, ws['gm_splits']):
+            call('vqa_grid_mean', ptr(m), layout, B, c, m.shape[2] * m.shape[3], ptr(ws['gmean']), self.Dv, col,
+                 ptr(ws['gm_part']), nsp, self.dt)
+            col += c
+
+    def _visual_forward(self, ws, maps, B, seed, p):
+        H, Dv = self.Hq, self.Dv
+        slab, sk, stride = self._gemm_slabs(ws['qT'], H, 1, self._w('gap1.0.weight'), H, 1, B, Dv, H)
+        call('vqa_gate_fwd', ptr(slab), sk, stride, ptr(self._f32('gap1.0.bias')), ptr(ws['gmean']), Dv,
+             ptr(ws['gate']), Dv, ptr(ws['pooled_d']), Dv, B, Dv, seed, p, self.dt)
+
+    def _visual_backward(self, ws, maps, B):
+        H, Dv = self.Hq, self.Dv
+        call('vqa_gate_bwd', ptr(ws['d_pooled']), Dv, ptr(ws['gmean']), Dv, ptr(ws['gate']), Dv, ptr(ws['dzg']), Dv,
+             B, Dv, self.dt)
+        call('vqa_colsum', ptr(ws['dzg']), Dv, ptr(self._g('gap1.0.bias')), B, Dv, self.dt)
+        self._wgrad(ws['dzg'], Dv, ws['qT'], H, 'gap1.0.weight', Dv, H, B)
+        self._bucket_done('gap1.0.weight')
+
+    def _w(self, name):
+        if name == 'gap1.0.weight':           # all gate weights as one (Dv, Hq) matrix
+            o = self._index[name][0]
+            src = self._shadow if self.dt == _lib.BF16 else self._flat
+            return src[o:o + self.Dv * self.Hq]
+        return super()._w(name)
+
+    def _f32(self, name):
+        if name == 'gap1.0.bias':
+            o = self._index[name][0]
+            return self._flat[o:o + self.Dv]
+        return super()._f32(name)
+
+    def _g(self, name):
+        if name in ('gap1.0.bias', 'gap1.0.weight'):
+            o = self._index[name][0]
+            return self._flat_grad[o:o + (self.Dv if name.endswith('bias') else self.Dv * self.Hq)]
+        return super()._g(name)
+
+
+class VQAModel(_VQAHeadModel):
+    """The reference's VQAModel (model.py:29-79) on the precomputed last ResNet map: a trainable
+    1x1 convolution to VISUAL_OUT / (H W) channels (model.py:53-54) whose NCHW output is viewed as
+    (B, VISUAL_OUT) (model.py:61).  ``input_v`` is the (B, 2048, H, W) map (or (B, H W, 2048)
+    channels-last rows); H W must divide VISUAL_OUT, as the reference's .view requires."""
+
+    def __init__(self, vocab_questions, vocab_answers, args=None, input_size: int = 512, *,
+                 map_channels: int = 2048, **kw):
+        self.Cin = int(map_channels)
+        self.R = int((input_size / 32) ** 2)               # output_size, model.py:53
+        kw.setdefault('visual_out', VISUAL_OUT)
+        if self.R < 1 or kw['visual_out'] % self.R:
+            raise ValueError('(input_size / 32)^2 must divide visual_out')
+        self.c_out = kw['visual_out'] // self.R
+        super().__init__(vocab_questions, vocab_answers, args, input_size, **kw)
+
+    def _build_visual(self, gen):
+        # index 0 stands where the reference keeps the frozen ResNet; index 1 is its Conv2d
+        self.visual = nn.Sequential(nn.Identity(), nn.Conv2d(self.Cin, self.c_out, 1))
+        conv = self.visual[1]
+        with torch.no_grad():
+            b = 1.0 / math.sqrt(self.Cin)
+            conv.weight.copy_((torch.rand(conv.weight.shape, generator=gen) * 2 - 1) * b)
+            conv.bias.copy_((torch.rand(conv.bias.shape, generator=gen) * 2 - 1) * b)
+
+    def _visual_trainable_order(self):
+        return [('visual.1.bias', self.visual[1].bias), ('visual.1.weight', self.visual[1].weight)]
+
+    def _visual_bucket_starts(self):
+        return ['visual.1.bias']
+
+    def _prepare_visual(self, input_v):
+        if input_v.dim() == 4:
+            B, Cin, Hh, Ww = input_v.shape
+            input_v = input_v.permute(0, 2, 3, 1).reshape(B, Hh * Ww, Cin)
+        if input_v.dim() != 3 or input_v.shape[2] != self.Cin or input_v.shape[1] != self.R:
+            raise ValueError(f'input_v must be (B, {self.Cin}, H, W) with H W = {self.R}, or (B, {self.R}, {self.Cin})')
+        feats = input_v.to(self.compute_dtype).contiguous()
+        return feats, feats.shape[0]
+
+    def _geometry(self, feats):
+        return feats.shape[1]
+
+    def _visual_workspace(self, ws, z, B, R):
+        cp = _pad8(self.c_out)
+        ws.update({'y': z((B * R, cp), self.compute_dtype), 'dy': z((B * R, cp), self.compute_dtype)})
+
+    def _visual_prologue(self, ws, feats, B):
+        pass
+
+    def _visual_forward(self, ws, feats, B, seed, p):
+        R, Cin, c, cp, dt = self.R, self.Cin, self.c_out, _pad8(self.c_out), self.dt
+        call('vqa_gemm_fused', ptr(feats), Cin, 1, ptr(self._w('visual.1.weight')), Cin, 1, ptr(ws['y']), cp,
+             B * R, c, Cin, ptr(self._f32('visual.1.bias')), None, 0, dt, dt, self.gemm_engine)
+        call('vqa_flatten_cm', ptr(ws['y']), cp, ptr(ws['pooled_d']), self.Dv, B, R, c, seed, p, dt)
+
+    def _visual_backward(self, ws, feats, B):
+        R, Cin, c, cp, dt = self.R, self.Cin, self.c_out, _pad8(self.c_out), self.dt
+        call('vqa_unflatten_cm', ptr(ws['d_pooled']), self.Dv, ptr(ws['dy']), cp, B, R, c, dt)
+        call('vqa_colsum', ptr(ws['dy']), cp, ptr(self._g('visual.1.bias')), B * R, c, dt)
+        self._wgrad(ws['dy'], cp, feats, Cin, 'visual.1.weight', c, Cin, B * R)
+        self._bucket_done('visual.1.weight')
