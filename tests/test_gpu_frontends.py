@@ -169,3 +169,34 @@ def test_gap_train_step_matches_oracle_adam():
     sd = m.state_dict()
     for k in names:
         assert rel_err(sd[k], po[k]) <= 2e-5, k
+
+
+def test_train_driver_gap_model_and_resume(tmp_path):
+    """The reference-CLI driver with --model VQAGAPModel on synthetic stage maps: loss falls; a run
+    resumed from the saved train state (weights + Adam moments + counters) continues bit-identically."""
+    import argparse
+    from vqa_amd import train as drv
+    from vqa_amd.model import VQAGAPModel
+    args = argparse.Namespace(model='VQAGAPModel', gpu=0)
+    dev = torch.device('cuda:0')
+    kw = dict(emb_size=20, question_out=48, fusion_in=32, fusion_hidden=16, gap_channels=(8, 16, 24, 32))
+    maps = ((8, 8), (16, 4), (24, 4), (32, 2))
+    tr = drv.SynthVQADataset(4, 32, 0, 0, 8, 50, 21, dev, seed=1, stage_maps=maps)
+    va = drv.SynthVQADataset(1, 32, 0, 0, 8, 50, 21, dev, seed=2, stage_maps=maps)
+
+    def fresh(seed=0):
+        return VQAGAPModel(['w'] * 50, ['a'] * 21, args, dtype=torch.float32, dropout=0.25, seed=seed, **kw).to(dev)
+
+    m = fresh()
+    hist = drv.train(m, tr, va, 6, 3e-3, args, out_dir=str(tmp_path / 'a'))
+    assert hist[-1]['train_loss'] < hist[0]['train_loss']
+    sd = torch.load(tmp_path / 'a' / 'ModelRunningRSVQA_VQAGAPModel.pth', weights_only=True)
+    assert 'gap3.0.weight' in sd and 'linear_v.weight' in sd and sd['linear_v.weight'].shape == (32, 80)
+    # 3 epochs, then 3 more from the saved state == 6 epochs in one go
+    m1 = fresh()
+    drv.train(m1, tr, va, 3, 3e-3, args, out_dir=str(tmp_path / 'b'))
+    m2 = fresh(seed=5)
+    drv.train(m2, tr, va, 6, 3e-3, args, out_dir=str(tmp_path / 'b'), resume=str(tmp_path / 'b' / 'TrainState_VQAGAPModel.pth'))
+    sa, sb = m.state_dict(), m2.state_dict()
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k

@@ -1,15 +1,16 @@
-"""MI355X-native VQA attention / fusion / classifier train step.
+"""MI355X-native VQA train step: question encoder, visual front-ends, fusion head, loss, Adam.
 
 HIP kernels (csrc/ -> libvqa_hip.so, C ABI in include/vqa_hip.h) driven from
 PyTorch-ROCm through ctypes.  There is no CPU fallback.
 """
 from .vocab_encoder import VocabEncoder  # noqa: F401
 
-__all__ = ['VocabEncoder', 'VQAAttnModel']
+_MODELS = ('VQAAttnModel', 'VQAGAPModel', 'VQAModel')
+__all__ = ['VocabEncoder', *_MODELS]
 
 
 def __getattr__(name):
-    if name == 'VQAAttnModel':
-        from .model import VQAAttnModel
-        return VQAAttnModel
+    if name in _MODELS:
+        from . import model
+        return getattr(model, name)
     raise AttributeError(name)

@@ -558,6 +558,31 @@ class _VQAHeadModel(nn.Module):
                 self.adam_step(lr, betas, eps, grad_scale=scale)
         return loss
 
+    def optimizer_state_dict(self) -> Dict[str, object]:
+        """Adam moments per parameter name plus the step / dropout counters (the reference
+        checkpoints the weights only, train.py:215-228; this makes a run resumable)."""
+        self._finish_pending()
+        out = {'step_count': self.step_count, 'drop_step': self.drop_step, 'base_seed': self.base_seed,
+               'exp_avg': {}, 'exp_avg_sq': {}}
+        if self._flat is not None and self._exp_avg is not None:
+            for name, (o, n, shape) in self._index.items():
+                out['exp_avg'][name] = self._exp_avg[o:o + n].view(shape).clone()
+                out['exp_avg_sq'][name] = self._exp_avg_sq[o:o + n].view(shape).clone()
+        return out
+
+    def load_optimizer_state_dict(self, state: Dict[str, object]) -> None:
+        self._finish_pending()
+        dev = next(self.parameters()).device
+        self._materialize(dev)
+        self.step_count, self.drop_step = int(state['step_count']), int(state['drop_step'])
+        self.base_seed = int(state.get('base_seed', self.base_seed))      # the dropout stream continues
+        self._exp_avg = torch.zeros_like(self._flat)
+        self._exp_avg_sq = torch.zeros_like(self._flat)
+        for name, (o, n, shape) in self._index.items():
+            if name in state['exp_avg']:
+                self._exp_avg[o:o + n].copy_(state['exp_avg'][name].reshape(-1).to(dev))
+                self._exp_avg_sq[o:o + n].copy_(state['exp_avg_sq'][name].reshape(-1).to(dev))
+
     # ------------------------------------------------------------------ torch plumbing
     def state_dict(self, *a, **kw):
         self._finish_pending()

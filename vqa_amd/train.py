@@ -2,6 +2,7 @@
 (vqa_model/train.py:241-252, vqa_model/test.py:119-128):
 
     python -m vqa_amd.train --model VQAAttnModel --dataset SYNTH --epochs 2 --bs 256 --gpu 0
+    (--model VQAGAPModel and --model VQAModel, the reference's class names, take precomputed ResNet maps)
 
 Same epoch structure as the reference (validation first, then training, train.py:48-228): per-epoch
 validation loss / OA / AA, running training loss = sum(loss * B) / len(dataset), best-on-validation and
@@ -17,7 +18,7 @@ import os
 import torch
 
 from .metrics import AccuracyMeter, HR_TYPES
-from .model import VQAAttnModel
+from .model import VQAAttnModel, VQAGAPModel, VQAModel
 from .parallel import GradReducer
 
 
@@ -25,11 +26,16 @@ class SynthVQADataset:
     """Synthetic stand-in for VQALoader: batches of (question int64 (B,L), answer int64 (B,),
     feats (B,R,Dv), type ids) already on the device (tuple order of VQALoader.py:176)."""
 
-    def __init__(self, n_batches, B, R, Dv, L, Vq, C, device, seed, dtype=torch.bfloat16):
+    def __init__(self, n_batches, B, R, Dv, L, Vq, C, device, seed, dtype=torch.bfloat16, stage_maps=None):
+        """stage_maps: ((C_k, grid_k), ...) makes the image item the list of NCHW stage maps that
+        VQAGAPModel takes instead of (B, R, Dv) region features."""
         g = torch.Generator(device=device).manual_seed(seed)
         self.batches = []
         for _ in range(n_batches):
-            feats = torch.randn((B, R, Dv), device=device, generator=g).clamp_min_(0).to(dtype)
+            if stage_maps:
+                feats = [torch.randn((B, c, s, s), device=device, generator=g).clamp_min_(0).to(dtype) for c, s in stage_maps]
+            else:
+                feats = torch.randn((B, R, Dv), device=device, generator=g).clamp_min_(0).to(dtype)
             lens = torch.randint(3, L + 1, (B,), device=device, generator=g)
             tok = torch.randint(1, Vq + 1, (B, L), device=device, generator=g)
             tok = torch.where(torch.arange(L, device=device)[None, :] < (lens[:, None] - 1), tok, torch.zeros_like(tok))
@@ -61,11 +67,18 @@ def evaluate(model, dataset, meter):
     return res
 
 
-def train(model, train_dataset, validate_dataset, num_epochs, learning_rate, args, Dataset='SYNTH', out_dir=None):
+def train(model, train_dataset, validate_dataset, num_epochs, learning_rate, args, Dataset='SYNTH', out_dir=None,
+          resume=None):
+    """resume: a TrainState_<model>.pth written by an earlier call (weights, Adam moments, epoch)."""
     meter = AccuracyMeter(HR_TYPES, device=next(model.parameters()).device)
     reducer = GradReducer()
-    min_val, best_epoch, history = float('inf'), 0, []
-    for epoch in range(num_epochs):
+    min_val, best_epoch, history, first_epoch = float('inf'), 0, [], 0
+    if resume:
+        st = torch.load(resume, weights_only=True)
+        model.load_state_dict(st['model'])
+        model.load_optimizer_state_dict(st['optimizer'])
+        first_epoch, min_val, best_epoch = int(st['epoch']) + 1, float(st['min_val']), int(st['best_epoch'])
+    for epoch in range(first_epoch, num_epochs):
         print('Epoch Number:', epoch)
         val = evaluate(model, validate_dataset, meter)
         print('epoch #%d val loss: %.3f' % (epoch, val['loss']))
@@ -85,6 +98,8 @@ def train(model, train_dataset, validate_dataset, num_epochs, learning_rate, arg
                 min_val, best_epoch = val['loss'], epoch
                 torch.save(model.state_dict(), f'{out_dir}/ModelBestRSVQA_{args.model}.pth')
             torch.save(model.state_dict(), f'{out_dir}/ModelRunningRSVQA_{args.model}.pth')
+            torch.save({'model': model.state_dict(), 'optimizer': model.optimizer_state_dict(), 'epoch': epoch,
+                        'min_val': min_val, 'best_epoch': best_epoch}, f'{out_dir}/TrainState_{args.model}.pth')
     return history
 
 
@@ -97,19 +112,26 @@ def main(argv=None):
     parser.add_argument('--model', type=str, required=True)
     parser.add_argument('--dataset', type=str, required=True)
     parser.add_argument('--out', type=str, default=None, help='checkpoint directory (reference: ../data/dump-models/<dataset>)')
+    parser.add_argument('--resume', type=str, default=None, help='TrainState_<model>.pth to continue from')
     args = parser.parse_args(argv)
-    if args.model != 'VQAAttnModel':
-        raise SystemExit('only --model VQAAttnModel is built on this path')
+    classes = {'VQAAttnModel': VQAAttnModel, 'VQAGAPModel': VQAGAPModel, 'VQAModel': VQAModel}
+    if args.model not in classes:
+        raise SystemExit('--model must be one of ' + ', '.join(classes))
     if args.dataset != 'SYNTH':
         raise SystemExit('only --dataset SYNTH is available (LR / HR need image files and a feature extractor)')
     dev = torch.device(f'cuda:{args.gpu}')
     torch.cuda.set_device(dev)
     Vq, C, L, R, Dv = 10000, 3000, 14, 196, 2048
-    train_ds = SynthVQADataset(8, args.bs, R, Dv, L, Vq, C, dev, seed=42)
-    val_ds = SynthVQADataset(2, args.bs, R, Dv, L, Vq, C, dev, seed=43)
-    model = VQAAttnModel(['<EOS>'] + [f'w{i}' for i in range(Vq - 1)], ['<EOS>'] + [f'a{i}' for i in range(C - 1)],
-                         args).to(dev)
-    return train(model, train_ds, val_ds, args.epochs, args.lr, args, args.dataset, args.out)
+    input_size, stage_maps = 512, None
+    if args.model == 'VQAGAPModel':       # ResNet-152 stage outputs of a 256 x 256 image (the LR tiles)
+        input_size, stage_maps = 256, ((256, 64), (512, 32), (1024, 16), (2048, 8))
+    elif args.model == 'VQAModel':        # last ResNet map of a 512 x 512 image: 16 x 16 x 2048
+        R = (input_size // 32) ** 2
+    train_ds = SynthVQADataset(8, args.bs, R, Dv, L, Vq, C, dev, seed=42, stage_maps=stage_maps)
+    val_ds = SynthVQADataset(2, args.bs, R, Dv, L, Vq, C, dev, seed=43, stage_maps=stage_maps)
+    model = classes[args.model](['<EOS>'] + [f'w{i}' for i in range(Vq - 1)], ['<EOS>'] + [f'a{i}' for i in range(C - 1)],
+                                args, input_size).to(dev)
+    return train(model, train_ds, val_ds, args.epochs, args.lr, args, args.dataset, args.out, args.resume)
 
 
 if __name__ == '__main__':
