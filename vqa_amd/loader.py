@@ -1,0 +1,88 @@
+"""Dataset over precomputed image features with the reference loader's item contract.
+
+Mirrors vqa_model/VQALoader.py:33-178 for the non-BERT models: the same three JSON files
+(``images`` with ``id / active / questions_ids``, ``questions`` with ``question / type /
+answers_ids``, ``answers`` with ``answer``), the same ``ratio_images_to_use`` cut (VQALoader.py:62-63),
+the same per-question item ``(question int16[L], answer int16[n], image, type_str)``
+(VQALoader.py:138, 176).  The image element is the precomputed feature array of the image
+(``<feature_dir>/<id>.npy``: (R, Dv) region features, or a ``.npz`` of stage maps for the gated
+pooling model) instead of the transformed .tif, because the ResNet lives outside this package.
+
+The reference's random flips / rotations of the image (VQALoader.py:147-155) have no counterpart:
+on precomputed features they would only permute the regions, which none of the front-ends here is
+sensitive to (mean and attention pooling are permutation invariant).
+"""
+from __future__ import annotations
+
+import json
+import os
+from typing import List, Sequence
+
+import numpy as np
+import torch
+
+
+class FeatureVQALoader(torch.utils.data.Dataset):
+    def __init__(self, feature_dir: str, images_file: str, questions_file: str, answers_file: str,
+                 encoder_questions, encoder_answers, train: bool = True, ratio_images_to_use: float = 1,
+                 cache_features: bool = True):
+        self.encoder_questions = encoder_questions
+        self.encoder_answers = encoder_answers
+        self.train = train
+        self.feature_dir = feature_dir
+        with open(questions_file) as fh:
+            self.questionsJSON = json.load(fh)
+        with open(answers_file) as fh:
+            self.answersJSON = json.load(fh)
+        with open(images_file) as fh:
+            self.imagesJSON = json.load(fh)
+
+        images = [img['id'] for img in self.imagesJSON['images'] if img['active']]
+        images = images[:int(len(images) * ratio_images_to_use)]
+        self.image_ids = images
+        self._cache = {} if cache_features else None
+
+        self.images_questions_answers: List[list] = []
+        for i, image in enumerate(images):
+            # the reference indexes the image list by id (VQALoader.py:70, 128): ids are positions
+            for qid in self.imagesJSON['images'][image]['questions_ids']:
+                question = self.questionsJSON['questions'][qid]
+                answer_str = self.answersJSON['answers'][question['answers_ids'][0]]['answer']
+                self.images_questions_answers.append([self.encoder_questions.encode(question['question']),
+                                                      self.encoder_answers.encode(answer_str), i, question['type']])
+        self.len = len(self.images_questions_answers)
+
+    def __len__(self):
+        return self.len
+
+    def _features(self, i: int):
+        if self._cache is not None and i in self._cache:
+            return self._cache[i]
+        base = os.path.join(self.feature_dir, str(self.image_ids[i]))
+        if os.path.exists(base + '.npy'):
+            f = torch.from_numpy(np.load(base + '.npy'))
+        else:
+            with np.load(base + '.npz') as z:
+                f = [torch.from_numpy(z[k]) for k in sorted(z.files)]
+        if self._cache is not None:
+            self._cache[i] = f
+        return f
+
+    def __getitem__(self, idx):
+        q = self.images_questions_answers[idx]
+        return np.array(q[0], dtype='int16'), np.array(q[1], dtype='int16'), self._features(q[2]), q[3]
+
+
+def collate(items: Sequence, device, type_names: Sequence[str], feature_dtype=torch.bfloat16):
+    """Batch preparation of train.py:176, 187-189: question.long() (B, L), answer.long().resize_(B),
+    the image element stacked and moved to the device, plus int32 question-type ids for the
+    on-device accuracy counters (the reference keeps the strings and counts in Python)."""
+    question = torch.from_numpy(np.stack([it[0] for it in items])).long().to(device)
+    answer = torch.from_numpy(np.stack([it[1][:1] for it in items])).long().reshape(len(items)).to(device)
+    first = items[0][2]
+    if isinstance(first, (list, tuple)):
+        image = [torch.stack([it[2][k] for it in items]).to(device=device, dtype=feature_dtype) for k in range(len(first))]
+    else:
+        image = torch.stack([it[2] for it in items]).to(device=device, dtype=feature_dtype)
+    types = torch.tensor([type_names.index(it[3]) for it in items], dtype=torch.int32, device=device)
+    return question, answer, image, types
