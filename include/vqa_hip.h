@@ -62,6 +62,25 @@ int vqa_lstm_cell(const float* slabs, int nslab, size_t slab_stride, const void*
                   void* h, int ld_h, const int32_t* lengths, float* q_f32, void* q_t, int ld_q,
                   int B, int H, int t, int L, int dtype, hipStream_t stream);
 
+/* Packed sequences (rows sorted by length so that the rows still running at step t are a prefix):
+ *   lengths as vqa_process_lengths; steps[b] = lengths[b], or L for an all-pad row (seq2vec.py:21: index
+ *   -1 selects the last step); perm[j] = original row of sorted row j (descending steps, ties in row
+ *   order); active[t] = #rows with steps > t; offsets[t] = sum of active[0:t], offsets[L] = their total.
+ *   One workgroup; B + 18 (L + 1) <= 16384.                        seq2vec.py:11-14, 16-25 */
+int vqa_sequence_pack(const int64_t* tokens, int B, int L, int32_t* lengths, int32_t* perm, int32_t* active,
+                      int32_t* offsets, hipStream_t stream);
+/* out[offsets[t] + j, 0:width] = table[tokens[perm[j], t], 0:width] for j < active[t]   seq2vec.py:42 */
+int vqa_embedding_gather_packed(const int64_t* tokens, const void* table, void* out, int B, int L, int width,
+                                int ld_table, int ld_out, int n_rows, const int32_t* perm, const int32_t* offsets,
+                                int dtype, hipStream_t stream);
+/* vqa_lstm_cell on packed sequences: state rows c, h and the slabs are in sorted order, only rows
+ * j < active[t] are updated, the input projection of row j is row offsets[t] + j of xg, and the
+ * selected output goes to q[perm[j]]. */
+int vqa_lstm_cell_packed(const float* slabs, int nslab, size_t slab_stride, const void* xg, int ld_xg, float* c,
+                         void* h, int ld_h, const int32_t* lengths, float* q_f32, void* q_t, int ld_q,
+                         int B, int H, int t, int L, const int32_t* perm, const int32_t* active,
+                         const int32_t* offsets, int dtype, hipStream_t stream);
+
 /* out[b, col0:col0+Ec] = l2norm(sum_t table[cap[b,t]] * (cap != 0) / max(#nonzero, 1e-9))
  *                      model.py:1571-1574 (mean_pooling), 1678 (F.normalize), 1734 (cat) */
 int vqa_caption_pool(const int64_t* cap_tokens, const void* table, void* out, int B, int Tc, int Ec,
@@ -125,6 +144,15 @@ int vqa_gemm_splitk_hint(int M, int N, int K, int a_kmajor, int b_kmajor);
 int vqa_gemm_slabs(const void* A, int lda, int a_kmajor, const void* B, int ldb, int b_kmajor, float* slabs,
                    size_t slab_stride, int ld_slab, int M, int N, int K, int splitk, int dtype, int engine,
                    hipStream_t stream);
+/* The same two products restricted to the first *active_rows rows of the output (a device-side
+ * count read by the kernel: workgroups whose first row is past it exit; rows past it inside a
+ * started tile may or may not be written).  active_rows may be NULL. */
+int vqa_gemm_slabs_rows(const void* A, int lda, int a_kmajor, const void* B, int ldb, int b_kmajor, float* slabs,
+                        size_t slab_stride, int ld_slab, int M, int N, int K, int splitk, int dtype, int engine,
+                        const int32_t* active_rows, hipStream_t stream);
+int vqa_gemm_fused_rows(const void* A, int lda, int a_kmajor, const void* B, int ldb, int b_kmajor, void* C, int ldc,
+                        int M, int N, int K, const float* bias, const float* row_scale, int act, int out_dtype,
+                        int dtype, int engine, const int32_t* active_rows, hipStream_t stream);
 /* C = act(row_scale[m] * (A B^T) + bias[n]); act 0 none, 1 tanh; bias / row_scale may be NULL */
 int vqa_gemm_fused(const void* A, int lda, int a_kmajor, const void* B, int ldb, int b_kmajor, void* C, int ldc,
                    int M, int N, int K, const float* bias, const float* row_scale, int act, int out_dtype,

@@ -170,12 +170,21 @@ def test_question_encoder_against_reference_fixture(golden_dir, dtype):
         ws = m._workspace(B, 1, L, 0, ids.device)
         torch.cuda.synchronize()
         assert np.array_equal(ws['len'].cpu().numpy(), z[f'{name}_lengths'].astype(np.int32))
-        # gather: time-major rows t*B+b, bit-exact against the table in the storage dtype
-        emb = ws['x_emb'].view(L, B, -1)[:, :, :E].permute(1, 0, 2).float().cpu()
+        # packed gather: row offs[t] + j holds the embedding of token t of sorted row j (= original row
+        # perm[j]) for the m_t[t] rows still running; bit-exact against the table in the storage dtype
+        ids_np = z[f'{name}_ids']
+        perm, m_t, offs = (ws[k].cpu().numpy() for k in ('perm', 'm_t', 'offs'))
         table = torch.from_numpy(z['embedding']).to(dtype).float()
-        assert torch.equal(emb, table[torch.from_numpy(z[f'{name}_ids'])])
-        if dtype == torch.float32:
-            assert torch.equal(emb, torch.from_numpy(z[f'{name}_emb']))
+        x_emb = ws['x_emb'][:, :E].float().cpu()
+        steps = np.where(z[f'{name}_lengths'] == 0, L, z[f'{name}_lengths'])
+        assert offs[L] == steps.sum()
+        for t in range(L):
+            rows = perm[:m_t[t]]
+            assert np.all(steps[rows] > t) and m_t[t] == (steps > t).sum()
+            got = x_emb[offs[t]:offs[t] + m_t[t]]
+            assert torch.equal(got, table[torch.from_numpy(ids_np[rows, t])])
+            if dtype == torch.float32:
+                assert torch.equal(got, torch.from_numpy(z[f'{name}_emb'])[torch.from_numpy(rows), t])
         assert rel_err(q, torch.from_numpy(z[f'{name}_last'])) <= tol
 
 
@@ -262,6 +271,34 @@ def test_deferred_last_bucket_is_exact(dtype):
     ma.eval(), mb.eval()
     with torch.no_grad():
         assert torch.equal(ma(args[0], args[1]), mb(args[0], args[1]))
+
+
+@pytest.mark.parametrize('B,L', [(1, 5), (37, 14), (256, 14), (1000, 20)])
+def test_sequence_pack_bit_exact(B, L):
+    """Lengths, the stable descending sort by step count, per-step live counts and their prefix sums
+    are integer work: exact against numpy.  Includes all-pad rows (they take all L steps) and
+    interior zeros (process_lengths counts zeros anywhere, seq2vec.py:11-14)."""
+    from vqa_amd import _lib
+    from vqa_amd._lib import call, ptr
+    rng = np.random.default_rng(B + L)
+    tok = rng.integers(1, 50, size=(B, L))
+    lens = rng.integers(0, L + 1, size=B)
+    tok[np.arange(L)[None, :] >= lens[:, None]] = 0
+    if B > 4:
+        tok[2, 1] = 0                                       # a zero in the middle of a question
+    t = torch.from_numpy(tok).cuda()
+    out = {k: torch.full((n,), -7, dtype=torch.int32, device='cuda') for k, n in
+           (('len', B), ('perm', B), ('m_t', L), ('offs', L + 1))}
+    _lib.bind_stream()
+    call('vqa_sequence_pack', ptr(t), B, L, ptr(out['len']), ptr(out['perm']), ptr(out['m_t']), ptr(out['offs']))
+    ln = L - (tok == 0).sum(1)
+    assert np.array_equal(out['len'].cpu().numpy(), vqa_ref.process_lengths(torch.from_numpy(tok)).numpy())
+    steps = np.where(ln == 0, L, ln)
+    perm = np.argsort(-steps, kind='stable')
+    m_t = np.array([(steps > s).sum() for s in range(L)])
+    assert np.array_equal(out['perm'].cpu().numpy(), perm)
+    assert np.array_equal(out['m_t'].cpu().numpy(), m_t)
+    assert np.array_equal(out['offs'].cpu().numpy(), np.concatenate([[0], np.cumsum(m_t)]))
 
 
 def test_argmax_and_counts_bit_exact(golden_dir):

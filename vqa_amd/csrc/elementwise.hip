@@ -25,6 +25,97 @@ __global__ void k_process_lengths(const int64_t* __restrict__ tok, int* __restri
     len[b] = L - z;
 }
 
+// Packed-sequence bookkeeping, one workgroup:
+//   len[b]   = L - #(tok[b,:] == 0)
+//   steps[b] = len[b] (an all-pad row takes all L steps: its last-step index -1 wraps to L - 1)
+//   perm     = rows ordered by descending steps, ties in row order (perm[j] = original row of sorted row j)
+//   m_t[t]   = rows still running at step t (a prefix of the sorted order); offs = its exclusive prefix sum,
+//              offs[L] = total number of (row, step) pairs
+__global__ void __launch_bounds__(1024) k_sequence_pack(const int64_t* __restrict__ tok, int B, int L,
+                                                        int* __restrict__ len, int* __restrict__ perm,
+                                                        int* __restrict__ m_t, int* __restrict__ offs) {
+    extern __shared__ int sm[];
+    int* steps = sm;                 // [B]   zero count, then step count
+    int* above = steps + B;          // [L+1] above[n] = rows with more than n steps (n = 0..L)
+    int* run = above + L + 1;        // [L+1] rows with exactly n steps placed by earlier chunks
+    int* wcnt = run + L + 1;         // [16][L+1] per-wave counts of the current chunk
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
+    for (int b = tid; b < B; b += blockDim.x) steps[b] = 0;
+    for (int n = tid; n <= L; n += blockDim.x) { above[n] = 0; run[n] = 0; }
+    __syncthreads();
+    for (long i = tid; i < (long)B * L; i += blockDim.x)              // coalesced pass over the tokens
+        if (tok[i] == 0) atomicAdd(&steps[i / L], 1);
+    __syncthreads();
+    for (int b = tid; b < B; b += blockDim.x) {
+        const int z = steps[b];
+        len[b] = L - z;
+        const int n = z == L ? L : L - z;
+        steps[b] = n;
+        atomicAdd(&run[n], 1);                                        // histogram (moved to `above` below)
+    }
+    __syncthreads();
+    for (int n = tid; n <= L; n += blockDim.x) {
+        int c = 0;
+        for (int k = n + 1; k <= L; ++k) c += run[k];
+        above[n] = c;
+    }
+    __syncthreads();
+    for (int n = tid; n <= L; n += blockDim.x) run[n] = 0;
+    for (int t = tid; t < L; t += blockDim.x) m_t[t] = above[t];
+    if (tid == 0) {
+        int o = 0;
+        for (int t = 0; t < L; ++t) { offs[t] = o; o += above[t]; }
+        offs[L] = o;
+    }
+    __syncthreads();
+    // stable placement, 1024 rows at a time: position = rows with more steps + equal-step rows before it
+    for (int b0 = 0; b0 < B; b0 += blockDim.x) {
+        const int b = b0 + tid;
+        const int n = b < B ? steps[b] : 0;                            // 0 never matches (steps >= 1)
+        int before = 0;
+        for (int k = 1; k <= L; ++k) {
+            const unsigned long long mask = __ballot(n == k);
+            if (n == k) before = __popcll(mask & ((1ull << lane) - 1ull));
+            if (lane == 0) wcnt[w * (L + 1) + k] = __popcll(mask);
+        }
+        __syncthreads();
+        if (b < B) {
+            int pos = above[n] + run[n] + before;
+            for (int ww = 0; ww < w; ++ww) pos += wcnt[ww * (L + 1) + n];
+            perm[pos] = b;
+        }
+        __syncthreads();
+        for (int k = 1 + tid; k <= L; k += blockDim.x) {
+            int c = 0;
+            for (int ww = 0; ww < nw; ++ww) c += wcnt[ww * (L + 1) + k];
+            run[k] += c;
+        }
+        __syncthreads();
+    }
+}
+
+// packed gather: row offs[t] + j of out = table[tok[perm[j], t]] for j < m_t[t]
+template <typename T>
+__global__ void k_embedding_gather_packed(const int64_t* __restrict__ tok, const T* __restrict__ table,
+                                          T* __restrict__ out, int B, int L, int width, int ld_table,
+                                          int ld_out, int n_rows, const int* __restrict__ perm,
+                                          const int* __restrict__ offs) {
+    const int vec_per_row = width >> 3;
+    const long total = (long)offs[L] * vec_per_row;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int v = (int)(i % vec_per_row);
+        const int prow = (int)(i / vec_per_row);
+        int t = 0;
+        while (t + 1 < L && offs[t + 1] <= prow) ++t;
+        const int b = perm[prow - offs[t]];
+        int64_t id = tok[(size_t)b * L + t];
+        if (id < 0 || id >= n_rows) id = 0;
+        float x[8];
+        Vec8<T>::load(table + (size_t)id * ld_table + v * 8, x);
+        Vec8<T>::store(out + (size_t)prow * ld_out + v * 8, x);
+    }
+}
+
 // out[row(b,t), 0:width] = table[tok[b,t], 0:width]; width % 8 == 0.
 // time_major: row = t * B + b, else row = b * L + t.  Ids outside the table
 // read the pad row 0.
@@ -72,14 +163,19 @@ __global__ void __launch_bounds__(256) k_lstm_cell(const float* __restrict__ sla
                             const T* __restrict__ xg, int ld_xg, float* __restrict__ c,
                             T* __restrict__ h, int ld_h, const int* __restrict__ len,
                             float* __restrict__ q32, T* __restrict__ qT, int ld_q,
-                            int B, int H, int t, int L) {
+                            int B, int H, int t, int L, const int* __restrict__ perm,
+                            const int* __restrict__ m_t, const int* __restrict__ offs) {
+    // packed mode (perm != null): state rows are in sorted order, only the first m_t[t] are live, their
+    // input-projection rows start at row offs[t] of xg and q goes to the original row perm[b]
     const int H4 = H >> 2;
-    const long total = (long)B * H4;
+    const int rows = perm ? m_t[t] : B;
+    const long xrow0 = perm ? offs[t] : 0;
+    const long total = (long)rows * H4;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int b = (int)(i / H4), j = (int)(i % H4) * 4;
         f32x4 g[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) g[k] = Vec4<T>::load(xg + (size_t)b * ld_xg + k * H + j);
+        for (int k = 0; k < 4; ++k) g[k] = Vec4<T>::load(xg + (size_t)(xrow0 + b) * ld_xg + k * H + j);
         for (int s = 0; s < nslab; ++s) {
             const float* sl = slabs + s * slab_stride + (size_t)b * 4 * H + j;
 #pragma unroll
@@ -97,11 +193,12 @@ __global__ void __launch_bounds__(256) k_lstm_cell(const float* __restrict__ sla
         }
         Vec4<float>::store(c + (size_t)b * H + j, cn);
         Vec4<T>::store(h + (size_t)b * ld_h + j, hn);
-        int last = len[b] - 1;
+        const int ob = perm ? perm[b] : b;
+        int last = len[ob] - 1;
         if (last < 0) last += L;               // all-pad row: negative index -> last step
         if (last == t) {
-            Vec4<float>::store(q32 + (size_t)b * ld_q + j, hn);
-            Vec4<T>::store(qT + (size_t)b * ld_q + j, hn);
+            Vec4<float>::store(q32 + (size_t)ob * ld_q + j, hn);
+            Vec4<T>::store(qT + (size_t)ob * ld_q + j, hn);
         }
     }
 }
@@ -476,6 +573,46 @@ int vqa_embedding_gather(const int64_t* tokens, const void* table, void* out, in
     return vqa_check_launch("vqa_embedding_gather");
 }
 
+int vqa_sequence_pack(const int64_t* tokens, int B, int L, int32_t* lengths, int32_t* perm, int32_t* active,
+                      int32_t* offsets, hipStream_t stream) {
+    VQA_REQUIRE(tokens && lengths && perm && active && offsets && B >= 0 && L > 0, "vqa_sequence_pack: bad arguments");
+    const size_t lds = (size_t)(B + 18 * (L + 1)) * sizeof(int);
+    VQA_REQUIRE(lds <= 64 * 1024, "vqa_sequence_pack: B + 18 (L + 1) must be <= 16384");
+    if (B == 0) return 0;
+    k_sequence_pack<<<1, 1024, lds, stream>>>(tokens, B, L, lengths, perm, active, offsets);
+    return vqa_check_launch("vqa_sequence_pack");
+}
+
+int vqa_embedding_gather_packed(const int64_t* tokens, const void* table, void* out, int B, int L, int width,
+                                int ld_table, int ld_out, int n_rows, const int32_t* perm, const int32_t* offsets,
+                                int dtype, hipStream_t stream) {
+    VQA_REQUIRE(tokens && table && out && perm && offsets && B >= 0 && L > 0 && n_rows > 0,
+                "vqa_embedding_gather_packed: bad arguments");
+    VQA_REQUIRE(width > 0 && width % 8 == 0 && ld_table % 8 == 0 && ld_out % 8 == 0 && width <= ld_table && width <= ld_out,
+                "vqa_embedding_gather_packed: width and leading dimensions must be multiples of 8");
+    if (B == 0) return 0;
+    const long total = (long)B * L * (width / 8);
+    DISPATCH_T(dtype, (k_embedding_gather_packed<T><<<grid_for(total, 256), 256, 0, stream>>>(
+        tokens, (const T*)table, (T*)out, B, L, width, ld_table, ld_out, n_rows, perm, offsets)));
+    return vqa_check_launch("vqa_embedding_gather_packed");
+}
+
+int vqa_lstm_cell_packed(const float* slabs, int nslab, size_t slab_stride, const void* xg, int ld_xg, float* c,
+                         void* h, int ld_h, const int32_t* lengths, float* q_f32, void* q_t, int ld_q,
+                         int B, int H, int t, int L, const int32_t* perm, const int32_t* active,
+                         const int32_t* offsets, int dtype, hipStream_t stream) {
+    VQA_REQUIRE(xg && c && h && lengths && q_f32 && q_t && perm && active && offsets && (nslab == 0 || slabs),
+                "vqa_lstm_cell_packed: null pointer");
+    VQA_REQUIRE(B >= 0 && H > 0 && t >= 0 && t < L && ld_xg >= 4 * H && ld_h >= H && ld_q >= H, "vqa_lstm_cell_packed: bad sizes");
+    VQA_REQUIRE(H % 4 == 0 && ld_xg % 4 == 0 && ld_h % 4 == 0 && ld_q % 4 == 0 && (slab_stride % 4 == 0 || nslab <= 1),
+                "vqa_lstm_cell_packed: H and leading dimensions must be multiples of 4");
+    if (B == 0) return 0;
+    DISPATCH_T(dtype, (k_lstm_cell<T><<<grid_for((long)B * (H / 4), 256), 256, 0, stream>>>(
+        slabs, nslab, slab_stride, (const T*)xg, ld_xg, c, (T*)h, ld_h, lengths, q_f32, (T*)q_t, ld_q, B, H, t, L,
+        perm, active, offsets)));
+    return vqa_check_launch("vqa_lstm_cell_packed");
+}
+
 int vqa_lstm_cell(const float* slabs, int nslab, size_t slab_stride, const void* xg_t, int ld_xg, float* c,
                   void* h, int ld_h, const int32_t* lengths, float* q_f32, void* q_t, int ld_q,
                   int B, int H, int t, int L, int dtype, hipStream_t stream) {
@@ -485,7 +622,8 @@ int vqa_lstm_cell(const float* slabs, int nslab, size_t slab_stride, const void*
                 "vqa_lstm_cell: H and leading dimensions must be multiples of 4");
     if (B == 0) return 0;
     DISPATCH_T(dtype, (k_lstm_cell<T><<<grid_for((long)B * (H / 4), 256), 256, 0, stream>>>(
-        slabs, nslab, slab_stride, (const T*)xg_t, ld_xg, c, (T*)h, ld_h, lengths, q_f32, (T*)q_t, ld_q, B, H, t, L)));
+        slabs, nslab, slab_stride, (const T*)xg_t, ld_xg, c, (T*)h, ld_h, lengths, q_f32, (T*)q_t, ld_q, B, H, t, L,
+        nullptr, nullptr, nullptr)));
     return vqa_check_launch("vqa_lstm_cell");
 }
 

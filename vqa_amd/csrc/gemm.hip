@@ -31,6 +31,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 struct Epi {
     void* out; int ld; int out_bf16; size_t split_stride;
     const float* bias; const float* row_scale; int act;
+    const int* m_limit;        // optional device-side row count: row tiles starting at or past *m_limit are not computed
     __device__ __forceinline__ float value(float v, float rs, float b) const {
         v = v * rs + b;
         if (act == 1) v = out_bf16 ? fast_tanh(v) : tanhf(v);
@@ -48,6 +49,19 @@ struct Epi {
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     const int q = nblk >> 3, r = nblk & 7, x = bid & 7;
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+
+// Logical workgroup id (or -1: nothing to do) and the number of output tiles per K split.  With a
+// device-side row limit only the row tiles below it count, and the XCD remap is applied to that
+// smaller set so that the live tiles stay spread over all eight XCDs.
+__device__ __forceinline__ int logical_block(const Epi& epi, int bm, int tiles_m, int tiles_n, bool remap, int& tiles) {
+    int tm = tiles_m;
+    const int nsplit = gridDim.x / (tiles_m * tiles_n);
+    if (epi.m_limit) tm = min(tiles_m, (*epi.m_limit + bm - 1) / bm);
+    tiles = tm * tiles_n;
+    const int nblk = tiles * nsplit;
+    if ((int)blockIdx.x >= nblk) return -1;
+    return remap ? xcd_remap(blockIdx.x, nblk) : (int)blockIdx.x;
 }
 
 // ---- LDS tile images ---------------------------------------------------------------
@@ -264,8 +278,9 @@ k_gemm_bf16(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B,
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wm = wave >> 1, wn = wave & 1;
-    const int L = xcd_remap(blockIdx.x, gridDim.x);
-    const int tiles = tiles_m * tiles_n;
+    int tiles;
+    const int L = logical_block(epi, BM, tiles_m, tiles_n, true, tiles);
+    if (L < 0) return;                                   // uniform over the workgroup, before any barrier
     const int split = L / tiles, ti = L % tiles;
     const int m0 = (ti / tiles_n) * BM, n0 = (ti % tiles_n) * BN;
     const int kbeg = split * k_per_split;
@@ -372,8 +387,9 @@ k_gemm_bf16_w8(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const int L = xcd_remap(blockIdx.x, gridDim.x);
-    const int tiles = tiles_m * tiles_n;
+    int tiles;
+    const int L = logical_block(epi, BM, tiles_m, tiles_n, true, tiles);
+    if (L < 0) return;
     const int split = L / tiles, ti = L % tiles;
     const int m0 = (ti / tiles_n) * BM, n0 = (ti % tiles_n) * BN;
     const int kbeg = split * k_per_split;
@@ -479,8 +495,10 @@ k_gemm_valu(const T* __restrict__ A, int lda, const T* __restrict__ B, int ldb, 
             int tiles_m, int tiles_n, int k_per_split, Epi epi) {
     __shared__ float As[16][68], Bs[16][68];
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-    const int tiles = tiles_m * tiles_n;
-    const int split = blockIdx.x / tiles, ti = blockIdx.x % tiles;
+    int tiles;
+    const int L = logical_block(epi, 64, tiles_m, tiles_n, false, tiles);
+    if (L < 0) return;
+    const int split = L / tiles, ti = L % tiles;
     const int m0 = (ti / tiles_n) * 64, n0 = (ti % tiles_n) * 64;
     const int kbeg = split * k_per_split, kend = min(K, kbeg + k_per_split);
     float acc[4][4] = {};
@@ -538,7 +556,11 @@ static inline int pick_tile(int M, int N, int K, int akm, int bkm, int engine) {
     // largest tile that still gives every CU a workgroup wins
     // (256 x 256 needs enough tiles, or enough K to split, to give most CUs a workgroup)
     const long split512 = t512 >= 200 ? 1 : (K / 256 < 256 / t512 ? K / 256 : 256 / t512);
-    if (M >= 384 && N >= 192 && t512 >= 32 && t512 * split512 >= 192) return 512;       // 256 x 256 tiles
+    // share of the last round of workgroups that is filled: a few more tiles than a multiple of 256
+    // leave most CUs idle for a whole tile time, the smaller tile then fills the chip better
+    const long b512 = t512 * split512, r512 = (b512 + 255) / 256 * 256, r256 = (t256 + 255) / 256 * 256;
+    const bool ragged = akm && bkm && b512 < 1024 && b512 * 4 < r512 * 3 && t256 * r512 > b512 * r256;
+    if (M >= 384 && N >= 192 && t512 >= 32 && t512 * split512 >= 192 && !ragged) return 512;       // 256 x 256 tiles
     if (akm && bkm && M >= 192 && N > 64 && t256 >= 40) return 256;   // 256 x 128 tiles, 3-stage ring
     return (M > 64 && N > 64 && t128 >= 40) ? 128 : 64;
 }
@@ -546,7 +568,10 @@ static inline int pick_tile(int M, int N, int K, int akm, int bkm, int engine) {
 static int launch_bf16(const void* A, int lda, int akm, const void* B, int ldb, int bkm, int M, int N, int K,
                        int splitk, int engine, const Epi& epi, hipStream_t stream) {
     int kps = ceil_div(ceil_div(K, splitk), GEMM_BK) * GEMM_BK;
-    const int bm = pick_tile(M, N, K, akm, bkm, engine);
+    // with a device-side row limit the live row count is unknown here: the tile is chosen for half the rows
+    // when there are many row tiles (a packed batch of sequences), for all of them otherwise
+    const int m_sched = (epi.m_limit && M >= 1024) ? M / 2 : M;
+    const int bm = pick_tile(m_sched, N, K, akm, bkm, engine);
     const bool big = bm == 128;
     const int bmr = bm >= 256 ? 256 : bm, bnr = bm == 512 ? 256 : (bm == 256 ? 128 : bm);
     const int tm = ceil_div(M, bmr), tn = ceil_div(N, bnr);
@@ -624,31 +649,45 @@ int vqa_gemm_splitk_hint(int M, int N, int K, int a_kmajor, int b_kmajor) {
     return s < 1 ? 1 : s;
 }
 
-int vqa_gemm_slabs(const void* A, int lda, int a_kmajor, const void* B, int ldb, int b_kmajor, float* slabs,
-                   size_t slab_stride, int ld_slab, int M, int N, int K, int splitk, int dtype, int engine,
-                   hipStream_t stream) {
+int vqa_gemm_slabs_rows(const void* A, int lda, int a_kmajor, const void* B, int ldb, int b_kmajor, float* slabs,
+                        size_t slab_stride, int ld_slab, int M, int N, int K, int splitk, int dtype, int engine,
+                        const int32_t* active_rows, hipStream_t stream) {
     if (int rc = gemm_check(A, lda, a_kmajor, B, ldb, b_kmajor, M, N, K, dtype, engine)) return rc;
     VQA_REQUIRE(slabs && splitk >= 1 && splitk <= 64 && ld_slab >= N, "vqa_gemm_slabs: bad slab arguments");
     VQA_REQUIRE(splitk == 1 || slab_stride >= (size_t)M * ld_slab, "vqa_gemm_slabs: slab_stride too small");
-    Epi epi{slabs, ld_slab, 0, slab_stride, nullptr, nullptr, 0};
+    Epi epi{slabs, ld_slab, 0, slab_stride, nullptr, nullptr, 0, active_rows};
     if (dtype == VQA_BF16 && engine != 1) launch_bf16(A, lda, a_kmajor, B, ldb, b_kmajor, M, N, K, splitk, engine, epi, stream);
     else if (dtype == VQA_BF16) launch_valu<bf16_t>(A, lda, a_kmajor, B, ldb, b_kmajor, M, N, K, splitk, epi, stream);
     else launch_valu<float>(A, lda, a_kmajor, B, ldb, b_kmajor, M, N, K, splitk, epi, stream);
     return vqa_check_launch("vqa_gemm_slabs");
 }
 
-int vqa_gemm_fused(const void* A, int lda, int a_kmajor, const void* B, int ldb, int b_kmajor, void* C, int ldc,
-                   int M, int N, int K, const float* bias, const float* row_scale, int act, int out_dtype,
-                   int dtype, int engine, hipStream_t stream) {
+int vqa_gemm_slabs(const void* A, int lda, int a_kmajor, const void* B, int ldb, int b_kmajor, float* slabs,
+                   size_t slab_stride, int ld_slab, int M, int N, int K, int splitk, int dtype, int engine,
+                   hipStream_t stream) {
+    return vqa_gemm_slabs_rows(A, lda, a_kmajor, B, ldb, b_kmajor, slabs, slab_stride, ld_slab, M, N, K, splitk, dtype,
+                               engine, nullptr, stream);
+}
+
+int vqa_gemm_fused_rows(const void* A, int lda, int a_kmajor, const void* B, int ldb, int b_kmajor, void* C, int ldc,
+                        int M, int N, int K, const float* bias, const float* row_scale, int act, int out_dtype,
+                        int dtype, int engine, const int32_t* active_rows, hipStream_t stream) {
     if (int rc = gemm_check(A, lda, a_kmajor, B, ldb, b_kmajor, M, N, K, dtype, engine)) return rc;
     VQA_REQUIRE(C && ldc >= N, "vqa_gemm_fused: bad output");
     VQA_REQUIRE(act == 0 || act == 1, "vqa_gemm_fused: act must be 0 (none) or 1 (tanh)");
     VQA_REQUIRE(out_dtype == VQA_F32 || out_dtype == VQA_BF16, "vqa_gemm_fused: out_dtype");
-    Epi epi{C, ldc, out_dtype == VQA_BF16, 0, bias, row_scale, act};
+    Epi epi{C, ldc, out_dtype == VQA_BF16, 0, bias, row_scale, act, active_rows};
     if (dtype == VQA_BF16 && engine != 1) launch_bf16(A, lda, a_kmajor, B, ldb, b_kmajor, M, N, K, 1, engine, epi, stream);
     else if (dtype == VQA_BF16) launch_valu<bf16_t>(A, lda, a_kmajor, B, ldb, b_kmajor, M, N, K, 1, epi, stream);
     else launch_valu<float>(A, lda, a_kmajor, B, ldb, b_kmajor, M, N, K, 1, epi, stream);
     return vqa_check_launch("vqa_gemm_fused");
+}
+
+int vqa_gemm_fused(const void* A, int lda, int a_kmajor, const void* B, int ldb, int b_kmajor, void* C, int ldc,
+                   int M, int N, int K, const float* bias, const float* row_scale, int act, int out_dtype,
+                   int dtype, int engine, hipStream_t stream) {
+    return vqa_gemm_fused_rows(A, lda, a_kmajor, B, ldb, b_kmajor, C, ldc, M, N, K, bias, row_scale, act, out_dtype,
+                               dtype, engine, nullptr, stream);
 }
 
 }  // extern "C"

@@ -283,7 +283,8 @@ class _VQAHeadModel(nn.Module):
             return torch.zeros(shape, dtype=dt, device=device)
 
         ws = {
-            'len': z((B,), torch.int32), 'x_emb': z((L * B, Ep), tdt), 'xg': z((L * B, 4 * H), tdt),
+            'len': z((B,), torch.int32), 'perm': z((B,), torch.int32), 'm_t': z((L,), torch.int32),
+            'offs': z((L + 1,), torch.int32), 'x_emb': z((L * B, Ep), tdt), 'xg': z((L * B, 4 * H), tdt),
             'c': z((B, H), f32), 'h': z((B, H), tdt), 'q32': z((B, H), f32), 'qT': z((B, H), tdt),
             'pooled_d': z((B, Dv), tdt), 'q_d': z((B, H), tdt),
             'xv': z((B, F), f32), 'xq': z((B, F), f32), 'x': z((B, F + Ec), tdt),
@@ -303,13 +304,14 @@ class _VQAHeadModel(nn.Module):
         return self._slab
 
     # ------------------------------------------------------------------ kernel helpers
-    def _gemm_slabs(self, A, lda, akm, Bm, ldb, bkm, M, N, K):
-        """fp32 partial sums of A B^T into the slab workspace -> (slab tensor, nslab, stride)."""
+    def _gemm_slabs(self, A, lda, akm, Bm, ldb, bkm, M, N, K, active_rows=None):
+        """fp32 partial sums of A B^T into the slab workspace -> (slab tensor, nslab, stride).
+        active_rows: device address of an int32 row count past which output tiles are skipped."""
         sk = call('vqa_gemm_splitk_hint', M, N, K, akm, bkm)
         stride = M * N
         slab = self._slabs(sk * stride, A.device)
-        call('vqa_gemm_slabs', ptr(A), lda, akm, ptr(Bm), ldb, bkm, ptr(slab), stride, N, M, N, K, sk,
-             self.dt, self.gemm_engine)
+        call('vqa_gemm_slabs_rows', ptr(A), lda, akm, ptr(Bm), ldb, bkm, ptr(slab), stride, N, M, N, K, sk,
+             self.dt, self.gemm_engine, active_rows)
         return slab, sk, stride
 
     def _linear(self, x, ldx, wname, bname, M, N, K, *, act=0, out_pre=None, ld_pre=0, out_post=None, ld_post=0,
@@ -382,20 +384,23 @@ class _VQAHeadModel(nn.Module):
         if ws is None:
             ws = self._workspace(B, 1, L, 0, dev)
         Ep, H, dt = _pad8(self.E), self.Hq, self.dt
-        call('vqa_process_lengths', ptr(tokens), ptr(ws['len']), B, L)
-        call('vqa_embedding_gather', ptr(tokens), ptr(self._emb_t), ptr(ws['x_emb']), B, L, Ep, Ep, Ep,
-             self._emb_t.shape[0], 1, dt)
-        call('vqa_gemm_fused', ptr(ws['x_emb']), Ep, 1, ptr(self._wih_t), Ep, 1, ptr(ws['xg']), 4 * H,
-             L * B, 4 * H, Ep, ptr(self._lstm_bias), None, 0, dt, dt, self.gemm_engine)
-        esz = ws['xg'].element_size()
+        # packed sequences: rows sorted by length, so the rows still running at step t are the first
+        # m_t[t] and their input projections are rows offs[t].. of xg; padding steps cost nothing
+        call('vqa_sequence_pack', ptr(tokens), B, L, ptr(ws['len']), ptr(ws['perm']), ptr(ws['m_t']), ptr(ws['offs']))
+        call('vqa_embedding_gather_packed', ptr(tokens), ptr(self._emb_t), ptr(ws['x_emb']), B, L, Ep, Ep, Ep,
+             self._emb_t.shape[0], ptr(ws['perm']), ptr(ws['offs']), dt)
+        total_rows = ws['offs'].data_ptr() + 4 * L
+        call('vqa_gemm_fused_rows', ptr(ws['x_emb']), Ep, 1, ptr(self._wih_t), Ep, 1, ptr(ws['xg']), 4 * H,
+             L * B, 4 * H, Ep, ptr(self._lstm_bias), None, 0, dt, dt, self.gemm_engine, total_rows)
         for t in range(L):
-            xg_t = ws['xg'].data_ptr() + t * B * 4 * H * esz
             if t == 0:
                 slab, sk, stride = None, 0, 0
             else:
-                slab, sk, stride = self._gemm_slabs(ws['h'], H, 1, self._whh_t, H, 1, B, 4 * H, H)
-            call('vqa_lstm_cell', ptr(slab), sk, stride, xg_t, 4 * H, ptr(ws['c']), ptr(ws['h']), H, ptr(ws['len']),
-                 ptr(ws['q32']), ptr(ws['qT']), H, B, H, t, L, dt)
+                slab, sk, stride = self._gemm_slabs(ws['h'], H, 1, self._whh_t, H, 1, B, 4 * H, H,
+                                                    active_rows=ws['m_t'].data_ptr() + 4 * t)
+            call('vqa_lstm_cell_packed', ptr(slab), sk, stride, ptr(ws['xg']), 4 * H, ptr(ws['c']), ptr(ws['h']), H,
+                 ptr(ws['len']), ptr(ws['q32']), ptr(ws['qT']), H, B, H, t, L, ptr(ws['perm']), ptr(ws['m_t']),
+                 ptr(ws['offs']), dt)
         return ws['q32']
 
     def _forward_impl(self, feats, tokens, captions):
