@@ -36,7 +36,7 @@ def make(M, N, K, akm, bkm, dtype, seed):
 SHAPES = [(37, 50, 72), (130, 70, 200), (300, 129, 64), (257, 384, 1000), (512, 136, 40), (64, 64, 8), (1, 9, 640)]
 
 
-@pytest.mark.parametrize('engine', [2, 3, 4, 6, 1])
+@pytest.mark.parametrize('engine', [2, 3, 4, 6, 8, 9, 1])
 @pytest.mark.parametrize('akm,bkm', [(1, 1), (1, 0), (0, 1), (0, 0)])
 def test_slab_gemm_all_layouts(engine, akm, bkm):
     for si, (M, N, K) in enumerate(SHAPES):
@@ -50,7 +50,7 @@ def test_slab_gemm_all_layouts(engine, akm, bkm):
             assert err <= 2e-5, (engine, akm, bkm, M, N, K, sk, err)
 
 
-@pytest.mark.parametrize('engine', [2, 3, 4, 6])
+@pytest.mark.parametrize('engine', [2, 3, 4, 6, 8, 9])
 @pytest.mark.parametrize('out_dtype', [torch.bfloat16, torch.float32])
 def test_fused_epilogue(engine, out_dtype):
     for si, (M, N, K) in enumerate([(300, 136, 256), (515, 1200, 192), (96, 8, 72)]):

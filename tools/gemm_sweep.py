@@ -22,11 +22,10 @@ def run(name, M, N, K, akm, bkm, variants):
     slab = torch.empty(max(v[1] for v in variants) * M * N, device='cuda', dtype=torch.float32)
     for eng, sk in variants:
         us = timeit(lambda: call('vqa_gemm_slabs', ptr(A), lda, int(akm), ptr(Bm), ldb, int(bkm), ptr(slab), M * N, N, M, N, K, sk, 1, eng))
-        print(f'{name:12s} M={M:6d} N={N:5d} K={K:6d} tile={ {2: "64", 3: "128", 4: "256x128", 6: "256x256"}[eng] } splitk={sk:2d}: {us:8.1f} us  {2.0 * M * N * K / us / 1e6:7.1f} TF')
+        print(f'{name:12s} M={M:6d} N={N:5d} K={K:6d} tile={ {2: "64", 3: "128", 4: "256x128", 6: "256x256", 8: "256x256r10", 9: "256x256r10pf"}[eng] } splitk={sk:2d}: {us:8.1f} us  {2.0 * M * N * K / us / 1e6:7.1f} TF')
 
 if __name__ == '__main__':
-    run('K4 fwd NT', 50176, 1200, 2048, True, True, [(3, 1), (4, 1), (6, 1)])
-    run('wgrad TN', 1200, 2048, 50176, False, False, [(3, 3), (4, 3), (6, 3), (6, 6)])
-    run('lstm NT', 256, 9600, 2400, True, True, [(4, 3), (6, 3), (6, 6)])
-    run('xg NT', 3584, 9600, 640, True, True, [(4, 1), (6, 1)])
-    run('cfg5 K4', 512 * 576, 1200, 2048, True, True, [(4, 1), (6, 1)])
+    for _ in range(2):
+        run('K4 fwd NT', 50176, 1200, 2048, True, True, [(6, 1), (8, 1), (9, 1)])
+        run('square', 8192, 8192, 8192, True, True, [(6, 1), (8, 1), (9, 1)])
+        run('wgrad TN', 1200, 2048, 50176, False, False, [(6, 6), (8, 6), (9, 6)])

@@ -73,22 +73,27 @@ __device__ __forceinline__ int logical_block(const Epi& epi, int bm, int tiles_m
 //   m-major [64][ROWS]: ROWS*2-byte rows, chunk ^= 2 * f(krow)     (ds_read_b64_tr_b16 fragments;
 //            a half-wave reads k-rows {r..r+3, r+8..r+11}: f spreads them over the 8 32-byte
 //            bank groups)
-template <int ROWS, bool KMAJOR> struct Tile;
-template <int ROWS> struct Tile<ROWS, true> {
-    static constexpr int BYTES = ROWS * 128;
+template <int ROWS, bool KMAJOR, int BK = 64> struct Tile;
+template <int ROWS, int BK> struct Tile<ROWS, true, BK> {
+    static constexpr int RBYTES = BK * 2;                   // bytes per tile row (128 or 64)
+    static constexpr int CPR = BK / 8;                      // 16-byte chunks per row
+    static constexpr int BYTES = ROWS * RBYTES;
     template <int NW> static constexpr int ni() { return BYTES / (NW * 1024); }   // DMA instructions per wave
-    static __device__ __forceinline__ int swz(int row) { return row & 7; }
-    static __device__ __forceinline__ int off(int row, int c) { return row * 128 + ((c ^ swz(row)) << 4); }
+    // 128-byte rows: chunk ^= row & 7.  64-byte rows: the four 16-lane groups of a ds_read_b128 fragment
+    // read rows {0-3, 12-15 | 4-11} with two chunk values; chunk ^= {0, 2, 3, 1}[(row >> 2) & 3] puts
+    // every group on 16 distinct 16-byte bank groups.
+    static __device__ __forceinline__ int swz(int row) { return BK == 64 ? (row & 7) : ((0x78 >> (((row >> 2) & 3) * 2)) & 3); }
+    static __device__ __forceinline__ int off(int row, int c) { return row * RBYTES + ((c ^ swz(row)) << 4); }
     // slot (instruction gi, lane) -> tile row and source chunk
     static __device__ __forceinline__ void slot(int gi, int lane, int& row, int& c) {
-        row = gi * 8 + (lane >> 3);
-        c = (lane & 7) ^ swz(row);
+        row = gi * (64 / CPR) + lane / CPR;
+        c = (lane % CPR) ^ swz(row);
     }
 };
-template <int ROWS> struct Tile<ROWS, false> {
+template <int ROWS, int BK> struct Tile<ROWS, false, BK> {
     static constexpr int RB = ROWS * 2;                     // bytes per k-row
     static constexpr int CPR = ROWS / 8;                    // chunks per k-row
-    static constexpr int BYTES = 64 * RB;
+    static constexpr int BYTES = BK * RB;
     template <int NW> static constexpr int ni() { return BYTES / (NW * 1024); }
     static __device__ __forceinline__ int swz(int krow) {
         return ROWS >= 128 ? (((krow & 3) | (((krow >> 3) & 1) << 2)) << 1)
@@ -104,14 +109,14 @@ template <int ROWS> struct Tile<ROWS, false> {
 
 // Source pointers of this lane's DMA slots for the tile at k = 0 (row / column indices past
 // the operand's extent are clamped: they only feed output rows / columns that are never stored).
-template <int ROWS, bool KMAJOR, int NW = 4>
+template <int ROWS, bool KMAJOR, int NW = 4, int BK = 64>
 __device__ __forceinline__ void dma_setup(const bf16_t* __restrict__ X, int ld, int row0, int nrows, int wave, int lane,
-                                          const bf16_t* (&src)[Tile<ROWS, KMAJOR>::template ni<NW>()]) {
-    constexpr int NI = Tile<ROWS, KMAJOR>::template ni<NW>();
+                                          const bf16_t* (&src)[Tile<ROWS, KMAJOR, BK>::template ni<NW>()]) {
+    constexpr int NI = Tile<ROWS, KMAJOR, BK>::template ni<NW>();
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         int r, c;
-        Tile<ROWS, KMAJOR>::slot(wave * NI + i, lane, r, c);
+        Tile<ROWS, KMAJOR, BK>::slot(wave * NI + i, lane, r, c);
         if (KMAJOR) {
             const int row = min(row0 + r, nrows - 1);
             src[i] = X + (size_t)row * ld + c * 8;
@@ -122,27 +127,28 @@ __device__ __forceinline__ void dma_setup(const bf16_t* __restrict__ X, int ld, 
     }
 }
 
-template <int ROWS, bool KMAJOR, int NW = 4>
-__device__ __forceinline__ void dma_issue(const bf16_t* const (&src)[Tile<ROWS, KMAJOR>::template ni<NW>()], size_t koff, char* lds, int wave) {
+template <int ROWS, bool KMAJOR, int NW = 4, int BK = 64>
+__device__ __forceinline__ void dma_issue(const bf16_t* const (&src)[Tile<ROWS, KMAJOR, BK>::template ni<NW>()], size_t koff, char* lds, int wave) {
     typedef __attribute__((address_space(1))) const void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
-    constexpr int NI = Tile<ROWS, KMAJOR>::template ni<NW>();
+    constexpr int NI = Tile<ROWS, KMAJOR, BK>::template ni<NW>();
 #pragma unroll
     for (int i = 0; i < NI; ++i)
         __builtin_amdgcn_global_load_lds((gptr_t)(src[i] + koff), (lptr_t)(lds + (wave * NI + i) * 1024), 16, 0, 0);
 }
 
 // register path (partial K tiles): global -> registers with zero fill, then -> the same LDS image
-template <int ROWS, bool KMAJOR, int NW = 4>
+template <int ROWS, bool KMAJOR, int NW = 4, int BK = 64>
 __device__ __forceinline__ void tile_load(const bf16_t* __restrict__ X, int ld, int row0, int nrows, int k0, int kend,
-                                          u32x4 (&r)[ROWS / (8 * NW)]) {
+                                          u32x4 (&r)[ROWS * BK / (512 * NW)]) {
     const int tid = threadIdx.x;
 #pragma unroll
-    for (int i = 0; i < ROWS / (8 * NW); ++i) {
+    for (int i = 0; i < ROWS * BK / (512 * NW); ++i) {
         const int q = tid + NW * 64 * i;
         u32x4 v = {0u, 0u, 0u, 0u};
         if (KMAJOR) {
-            const int row = row0 + (q >> 3), k = k0 + ((q & 7) << 3);
+            constexpr int CPR = BK / 8;
+            const int row = row0 + q / CPR, k = k0 + ((q % CPR) << 3);
             if (row < nrows && k < kend) v = *reinterpret_cast<const u32x4*>(X + (size_t)row * ld + k);
         } else {
             constexpr int CPR = ROWS / 8;
@@ -153,33 +159,33 @@ __device__ __forceinline__ void tile_load(const bf16_t* __restrict__ X, int ld, 
     }
 }
 
-template <int ROWS, bool KMAJOR, int NW = 4>
-__device__ __forceinline__ void tile_store(char* lds, const u32x4 (&r)[ROWS / (8 * NW)]) {
+template <int ROWS, bool KMAJOR, int NW = 4, int BK = 64>
+__device__ __forceinline__ void tile_store(char* lds, const u32x4 (&r)[ROWS * BK / (512 * NW)]) {
     const int tid = threadIdx.x;
 #pragma unroll
-    for (int i = 0; i < ROWS / (8 * NW); ++i) {
+    for (int i = 0; i < ROWS * BK / (512 * NW); ++i) {
         const int q = tid + NW * 64 * i;
         int off;
-        if (KMAJOR) off = Tile<ROWS, true>::off(q >> 3, q & 7);
-        else off = Tile<ROWS, false>::off(q / (ROWS / 8), q % (ROWS / 8));
+        if (KMAJOR) off = Tile<ROWS, true, BK>::off(q / (BK / 8), q % (BK / 8));
+        else off = Tile<ROWS, false, BK>::off(q / (ROWS / 8), q % (ROWS / 8));
         *reinterpret_cast<u32x4*>(lds + off) = r[i];
     }
 }
 
 // fragment of the 16 tile rows starting at r0 for K sub-step kk (32 k's)
-template <int ROWS, bool KMAJOR>
+template <int ROWS, bool KMAJOR, int BK = 64>
 __device__ __forceinline__ bf16x8_t frag_read(const char* lds, int r0, int kk, int lane) {
     if (KMAJOR) {
-        return *reinterpret_cast<const bf16x8_t*>(lds + Tile<ROWS, true>::off(r0 + (lane & 15), kk * 4 + (lane >> 4)));
+        return *reinterpret_cast<const bf16x8_t*>(lds + Tile<ROWS, true, BK>::off(r0 + (lane & 15), kk * 4 + (lane >> 4)));
     } else {
         const int g = lane >> 4, li = lane & 15;
         const int krow = kk * 32 + 8 * g + (li >> 2);
         const int col = r0 + 4 * (li & 3);
         typedef s16x4_t __attribute__((address_space(3))) * lds_p;
         // rows krow and krow + 4 have the same swizzle (it ignores bit 2 of the row)
-        const int off = Tile<ROWS, false>::off(krow, col >> 3) + (col & 7) * 2;
+        const int off = Tile<ROWS, false, BK>::off(krow, col >> 3) + (col & 7) * 2;
         const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(lds + off));
-        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(lds + off + 4 * Tile<ROWS, false>::RB));
+        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(lds + off + 4 * Tile<ROWS, false, BK>::RB));
         s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         return __builtin_bit_cast(bf16x8_t, v);
     }
@@ -488,6 +494,131 @@ k_gemm_bf16_w8(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__
     epilogue_store<MT, NT>(lds, acc, epi, split, m0 + wm * WMR, n0 + wn * 64, M, N, wave, lane);
 }
 
+// ---- 256 x 256 tiles, ring of ten quarter-operand slots ------------------------------------
+// A K tile (64 wide) is four 16 KiB quarters: A rows 0-127, A rows 128-255, B columns 0-127, B columns
+// 128-255, each a Tile<128, ., 64> image (whole 128-byte lines on the k-major side).  The ring holds
+// ten quarters = 2.5 K tiles = all 160 KiB of LDS: while tile t is consumed, tile t + 1 and half of
+// tile t + 2 are resident or in flight, and the four slots tile t - 1 occupied are refilled at once,
+// so the DMA queue never drains (a two-slot ring waits for every tile with an empty queue, which
+// costs about half the fetch rate).  One counted wait + raw barrier per K tile.
+template <bool AKM, bool BKM, int PF>
+__global__ void __launch_bounds__(512)
+k_gemm_bf16_r10(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, int M, int N, int K,
+                int tiles_m, int tiles_n, int k_per_split, Epi epi) {
+    constexpr int BM = 256, BN = 256, NW = 8, NQ = 10, QB = 16384;
+    typedef Tile<128, AKM> TA;
+    typedef Tile<128, BKM> TB;
+    static_assert(TA::BYTES == QB && TB::BYTES == QB, "quarter size");
+    constexpr int MT = 8, NT = 4;
+    constexpr int EPI_BYTES = NW * 32 * (64 + 4) * 4;
+    static_assert(NQ * QB >= EPI_BYTES, "ring must hold the store staging area");
+    __shared__ __attribute__((aligned(1024))) char lds[NQ * QB];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wm = wave >> 2, wn = wave & 3;
+    int tiles;
+    const int L = logical_block(epi, BM, tiles_m, tiles_n, true, tiles);
+    if (L < 0) return;
+    const int split = L / tiles, ti = L % tiles;
+    const int m0 = (ti / tiles_n) * BM, n0 = (ti % tiles_n) * BN;
+    const int kbeg = split * k_per_split;
+    const int kend = min(K, kbeg + k_per_split);
+    const int nk = kend > kbeg ? (kend - kbeg + GEMM_BK - 1) / GEMM_BK : 0;
+    const int nfull = kend > kbeg ? (kend - kbeg) / GEMM_BK : 0;      // tiles [0, nfull) come by DMA
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // two DMA instructions per wave and quarter
+    const bf16_t* sa0[2]; const bf16_t* sa1[2]; const bf16_t* sb0[2]; const bf16_t* sb1[2];
+    dma_setup<128, AKM, NW>(A, lda, m0, M, wave, lane, sa0);
+    dma_setup<128, AKM, NW>(A, lda, m0 + 128, M, wave, lane, sa1);
+    dma_setup<128, BKM, NW>(B, ldb, n0, N, wave, lane, sb0);
+    dma_setup<128, BKM, NW>(B, ldb, n0 + 128, N, wave, lane, sb1);
+    const size_t ka = AKM ? 1 : (size_t)lda, kb = BKM ? 1 : (size_t)ldb;
+
+    // quarter q = 4 * tile + j lives in slot q % 10; slot of (tile t, j):
+    auto slot_of = [&](int t, int j) { return lds + ((4 * t + j) % NQ) * QB; };
+    auto issue_half = [&](int t, int h) {                 // h = 0: both A quarters, h = 1: both B quarters
+        const int k0 = kbeg + t * GEMM_BK;
+        if (h == 0) {
+            dma_issue<128, AKM, NW>(sa0, k0 * ka, slot_of(t, 0), wave);
+            dma_issue<128, AKM, NW>(sa1, k0 * ka, slot_of(t, 1), wave);
+        } else {
+            dma_issue<128, BKM, NW>(sb0, k0 * kb, slot_of(t, 2), wave);
+            dma_issue<128, BKM, NW>(sb1, k0 * kb, slot_of(t, 3), wave);
+        }
+    };
+    auto compute = [&](const char* la, const char* lb) {  // la: this wave's A quarter, lb: its B quarter
+        const int bc = (wn & 1) * 64;
+        if (PF) {
+            bf16x8_t fa[2][MT], fb[2][NT];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) fb[kk][j] = frag_read<128, BKM>(lb, bc + j * 16, kk, lane);
+#pragma unroll
+                for (int i = 0; i < MT; ++i) fa[kk][i] = frag_read<128, AKM>(la, i * 16, kk, lane);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[kk][i], fb[kk][j], acc[i][j], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8_t fa[MT], fb[NT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) fa[i] = frag_read<128, AKM>(la, i * 16, kk, lane);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) fb[j] = frag_read<128, BKM>(lb, bc + j * 16, kk, lane);
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    };
+
+    // prologue: quarters 0..5 = tile 0 and the A half of tile 1
+    if (nfull > 0) { issue_half(0, 0); issue_half(0, 1); }
+    if (nfull > 1) issue_half(1, 0);
+    for (int it = 0; it < nfull; ++it) {
+        // issued so far: quarters [0, 4 it + 6).  Tile `it` must have landed; the A half of tile it + 1 (4 DMA
+        // instructions per wave) stays in flight across the barrier.  The barrier also tells that every wave is
+        // done with tile it - 1, whose four slots now take quarters 4 it + 6 .. 4 it + 9: the B half of tile it + 1
+        // and the A half of tile it + 2.
+        if (it + 1 < nfull) VMCNT_BARRIER(4); else VMCNT_BARRIER(0);
+        if (it + 1 < nfull) issue_half(it + 1, 1);
+        if (it + 2 < nfull) issue_half(it + 2, 0);
+        compute(slot_of(it, wm), slot_of(it, 2 + (wn >> 1)));
+    }
+    if (nk > nfull) {                                       // partial last K tile through registers, into slots 0..3
+        VMCNT_BARRIER(0);
+        u32x4 ra[2], rb[2];
+        const int k0 = kbeg + nfull * GEMM_BK;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            tile_load<128, AKM, NW>(A, lda, m0 + 128 * h, M, k0, kend, ra);
+            tile_load<128, BKM, NW>(B, ldb, n0 + 128 * h, N, k0, kend, rb);
+            tile_store<128, AKM, NW>(lds + h * QB, ra);
+            tile_store<128, BKM, NW>(lds + (2 + h) * QB, rb);
+        }
+        VMCNT_BARRIER(0);
+        compute(lds + wm * QB, lds + (2 + (wn >> 1)) * QB);
+    }
+    VMCNT_BARRIER(0);
+    epilogue_store<MT, NT>(lds, acc, epi, split, m0 + wm * 128, n0 + wn * 64, M, N, wave, lane);
+}
+
 // ---- fp32 / any-stride VALU kernel -----------------------------------------------
 template <typename T, bool AKM, bool BKM>
 __global__ void __launch_bounds__(256)
@@ -549,6 +680,8 @@ static inline int pick_tile(int M, int N, int K, int akm, int bkm, int engine) {
     if (engine == 3) return 128;
     if (engine == 4) return 256;
     if (engine == 6) return 512;                          // 256 x 256 tiles
+    if (engine == 8) return 2048;                         // 256 x 256 tiles, ten-quarter ring
+    if (engine == 9) return 4096;                         // same, all fragments of a K tile read before its MFMAs
     const long t128 = (long)ceil_div(M, 128) * ceil_div(N, 128);
     const long t256 = (long)ceil_div(M, 256) * ceil_div(N, 128);
     const long t512 = (long)ceil_div(M, 256) * ceil_div(N, 256);
@@ -560,7 +693,9 @@ static inline int pick_tile(int M, int N, int K, int akm, int bkm, int engine) {
     // leave most CUs idle for a whole tile time, the smaller tile then fills the chip better
     const long b512 = t512 * split512, r512 = (b512 + 255) / 256 * 256, r256 = (t256 + 255) / 256 * 256;
     const bool ragged = akm && bkm && b512 < 1024 && b512 * 4 < r512 * 3 && t256 * r512 > b512 * r256;
-    if (M >= 384 && N >= 192 && t512 >= 32 && t512 * split512 >= 192 && !ragged) return 512;       // 256 x 256 tiles
+    // 256 x 256 tiles (the ten-quarter ring variant, engine 8 / 9, is 6-8 % faster at 8192^3 but not at this step's
+    // K = 2048 shapes, where it measured 1.5 % slower inside the step)
+    if (M >= 384 && N >= 192 && t512 >= 32 && t512 * split512 >= 192 && !ragged) return 512;
     if (akm && bkm && M >= 192 && N > 64 && t256 >= 40) return 256;   // 256 x 128 tiles, 3-stage ring
     return (M > 64 && N > 64 && t128 >= 40) ? 128 : 64;
 }
@@ -573,10 +708,21 @@ static int launch_bf16(const void* A, int lda, int akm, const void* B, int ldb, 
     const int m_sched = (epi.m_limit && M >= 1024) ? M / 2 : M;
     const int bm = pick_tile(m_sched, N, K, akm, bkm, engine);
     const bool big = bm == 128;
-    const int bmr = bm >= 256 ? 256 : bm, bnr = bm == 512 ? 256 : (bm == 256 ? 128 : bm);
+    const int bmr = bm >= 256 ? 256 : bm, bnr = bm >= 512 ? 256 : (bm == 256 ? 128 : bm);
     const int tm = ceil_div(M, bmr), tn = ceil_div(N, bnr);
     const unsigned grid = (unsigned)(tm * tn * splitk);
     const bf16_t* a = (const bf16_t*)A; const bf16_t* b = (const bf16_t*)B;
+    if (bm == 2048 || bm == 4096) {
+#define LAUNCHR(AK, BK_)                                                                                              \
+    do { if (bm == 2048) k_gemm_bf16_r10<AK, BK_, 0><<<grid, 512, 0, stream>>>(a, lda, b, ldb, M, N, K, tm, tn, kps, epi); \
+         else k_gemm_bf16_r10<AK, BK_, 1><<<grid, 512, 0, stream>>>(a, lda, b, ldb, M, N, K, tm, tn, kps, epi); } while (0)
+        if (akm && bkm) LAUNCHR(true, true);
+        else if (akm && !bkm) LAUNCHR(true, false);
+        else if (!akm && bkm) LAUNCHR(false, true);
+        else LAUNCHR(false, false);
+#undef LAUNCHR
+        return 0;
+    }
     if (bm >= 256) {
 #define LAUNCH8(AK, BK_)                                                                                             \
     do { if (bm == 256) k_gemm_bf16_w8<AK, BK_, 128><<<grid, 512, 0, stream>>>(a, lda, b, ldb, M, N, K, tm, tn, kps, epi); \
@@ -641,7 +787,7 @@ extern "C" {
 // keeping at least 4 (128-tile) / 4 (64-tile) K steps of 64 per split
 int vqa_gemm_splitk_hint(int M, int N, int K, int a_kmajor, int b_kmajor) {
     const int bm = pick_tile(M, N, K, a_kmajor, b_kmajor, 0);
-    const long tiles = (long)ceil_div(M, bm >= 256 ? 256 : bm) * ceil_div(N, bm == 512 ? 256 : (bm == 256 ? 128 : bm));
+    const long tiles = (long)ceil_div(M, bm >= 256 ? 256 : bm) * ceil_div(N, bm >= 512 ? 256 : (bm == 256 ? 128 : bm));
     int s = (int)((bm >= 256 ? 256 : 512) / tiles);   // one round of workgroups: 1 per CU (256 tiles) or 2 per CU
     const int maxs = K / 256 > 0 ? K / 256 : 1;
     if (s > maxs) s = maxs;
