@@ -69,17 +69,19 @@ int vqa_lstm_cell(const float* slabs, int nslab, size_t slab_stride, const void*
  *   One workgroup; B + 18 (L + 1) <= 16384.                        seq2vec.py:11-14, 16-25 */
 int vqa_sequence_pack(const int64_t* tokens, int B, int L, int32_t* lengths, int32_t* perm, int32_t* active,
                       int32_t* offsets, hipStream_t stream);
-/* out[offsets[t] + j, 0:width] = table[tokens[perm[j], t], 0:width] for j < active[t]   seq2vec.py:42 */
+/* out[offsets[t] + j, 0:width] = act(table[tokens[perm[j], t], 0:width]) for j < active[t]; act 0 none,
+ * 1 tanh (TwoLSTM applies tanh to the embeddings)                  seq2vec.py:42, 63-64 */
 int vqa_embedding_gather_packed(const int64_t* tokens, const void* table, void* out, int B, int L, int width,
                                 int ld_table, int ld_out, int n_rows, const int32_t* perm, const int32_t* offsets,
-                                int dtype, hipStream_t stream);
+                                int act, int dtype, hipStream_t stream);
 /* vqa_lstm_cell on packed sequences: state rows c, h and the slabs are in sorted order, only rows
  * j < active[t] are updated, the input projection of row j is row offsets[t] + j of xg, and the
- * selected output goes to q[perm[j]]. */
+ * selected output goes to q[perm[j]].  hs (optional) receives every step's output at the packed
+ * row offsets[t] + j: the input sequence of a stacked second layer (seq2vec.py:65, 70). */
 int vqa_lstm_cell_packed(const float* slabs, int nslab, size_t slab_stride, const void* xg, int ld_xg, float* c,
                          void* h, int ld_h, const int32_t* lengths, float* q_f32, void* q_t, int ld_q,
                          int B, int H, int t, int L, const int32_t* perm, const int32_t* active,
-                         const int32_t* offsets, int dtype, hipStream_t stream);
+                         const int32_t* offsets, void* hs, int ld_hs, int dtype, hipStream_t stream);
 
 /* out[b, col0:col0+Ec] = l2norm(sum_t table[cap[b,t]] * (cap != 0) / max(#nonzero, 1e-9))
  *                      model.py:1571-1574 (mean_pooling), 1678 (F.normalize), 1734 (cat) */

@@ -136,6 +136,42 @@ def g2_seq2vec():
     print('G2 seq2vec: embedding', out['embedding'].shape, 'row0 zero:', bool((out['embedding'][0] == 0).all()))
 
 
+def g2b_two_lstm():
+    """The reference's TwoLSTM (seq2vec.py:48-76): its own embedding / rnn_0 / rnn_1 sub-modules, tanh on
+    the embeddings, select_last of both layers, concatenation (eval mode: no dropout), run along the
+    token axis, plus the forward as committed (which recurs along the batch axis)."""
+    sys.modules.setdefault('skipthoughts', types.ModuleType('skipthoughts'))
+    import seq2vec as ref_s2v
+    torch.manual_seed(43)
+    vocab = ['robots', 'are', 'very', 'cool', '<eos>', 'BiDiBu']          # seq2vec.py:102
+    E, H = 20, 16
+    m = ref_s2v.TwoLSTM(vocab, E, H).eval()
+    ids_main = torch.LongTensor([[1, 2, 3, 4, 5, 0, 0], [6, 1, 2, 3, 3, 4, 5], [6, 1, 2, 3, 3, 4, 5]])  # seq2vec.py:105-109
+    g = torch.Generator().manual_seed(8)
+    ids_rand = torch.randint(1, 7, (9, 14), generator=g)
+    lens = torch.tensor([14, 13, 9, 3, 1, 0, 7, 14, 2])
+    ids_rand = torch.where(torch.arange(14)[None, :] < lens[:, None], ids_rand, torch.zeros_like(ids_rand))
+    out = {'embedding': m.embedding.weight.detach().numpy()}
+    for li, rnn in enumerate((m.rnn_0, m.rnn_1)):
+        for k in ('weight_ih_l0', 'weight_hh_l0', 'bias_ih_l0', 'bias_hh_l0'):
+            out[f'rnn_{li}.{k}'] = getattr(rnn, k).detach().numpy()
+    for name, ids in (('main', ids_main), ('rand', ids_rand)):
+        with torch.no_grad():
+            lengths = [int(x) for x in ref_s2v.process_lengths(ids)]
+            e = torch.tanh(m.embedding(ids))                       # seq2vec.py:63-64
+            x0, _ = m.rnn_0(e.transpose(0, 1))                     # time-major recurrence
+            x1, _ = m.rnn_1(x0)
+            v0 = ref_s2v.select_last(x0.transpose(0, 1).contiguous().clone(), lengths)
+            v1 = ref_s2v.select_last(x1.transpose(0, 1).contiguous().clone(), lengths)
+            as_written = m(ids)
+        out[f'{name}_ids'] = ids.numpy()
+        out[f'{name}_lengths'] = np.array(lengths)
+        out[f'{name}_last'] = torch.cat((v0, v1), 1).numpy()       # seq2vec.py:75
+        out[f'{name}_as_written'] = as_written.numpy()
+    np.savez(os.path.join(OUT, 'g2b_two_lstm.npz'), **out)
+    print('G2b TwoLSTM:', out['rand_last'].shape)
+
+
 TINY = dict(vq=30, C=11, E=12, Hq=24, Dv=32, A=16, F=16, Hf=8)
 
 
@@ -190,5 +226,6 @@ if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     g1_vocab()
     g2_seq2vec()
+    g2b_two_lstm()
     g3_model()
     g5_ce_g6_metrics()

@@ -120,7 +120,20 @@ def lstm_time_major(e: torch.Tensor, w_ih, w_hh, b_ih, b_hh) -> torch.Tensor:
     return torch.stack(outs, 1)
 
 
-def encode_question(tokens, p: Dict[str, torch.Tensor]) -> torch.Tensor:
+def encode_question(tokens, p: Dict[str, torch.Tensor], drop_seeds=(None, None), drop_p: float = 0.3) -> torch.Tensor:
+    """seq2vec.LSTM (seq2vec.py:40-45) or, when the parameters hold ``rnn_0`` / ``rnn_1``, TwoLSTM
+    (seq2vec.py:61-76): tanh on the embeddings, two stacked LSTMs, select_last of each layer's
+    outputs, dropout(0.3) on each vector in training mode, concatenation."""
+    if 'seq2vec.rnn_0.weight_ih_l0' in p:
+        e = torch.tanh(embedding_gather(tokens, p['seq2vec.embedding.weight']))
+        x = e
+        vecs = []
+        lengths = process_lengths(tokens)
+        for li in range(2):
+            pre = f'seq2vec.rnn_{li}.'
+            x = lstm_time_major(x, p[pre + 'weight_ih_l0'], p[pre + 'weight_hh_l0'], p[pre + 'bias_ih_l0'], p[pre + 'bias_hh_l0'])
+            vecs.append(apply_dropout(select_last(x, lengths), drop_seeds[li], drop_p))
+        return torch.cat(vecs, dim=1)
     e = embedding_gather(tokens, p['seq2vec.embedding.weight'])
     hs = lstm_time_major(e, p['seq2vec.rnn.weight_ih_l0'], p['seq2vec.rnn.weight_hh_l0'],
                          p['seq2vec.rnn.bias_ih_l0'], p['seq2vec.rnn.bias_hh_l0'])
@@ -194,8 +207,9 @@ def forward(p: Dict[str, torch.Tensor], feats, tokens: torch.Tensor,
     x = drop(tanh(linear_classif1(x))); logits = linear_classif2(x).
     drop_seeds = (seed_v, seed_q, seed_f1, seed_f2) or None for eval mode.
     """
-    ds = drop_seeds if drop_seeds is not None else (None, None, None, None)
-    q = encode_question(tokens, p)
+    ds = tuple(drop_seeds) if drop_seeds is not None else (None, None, None, None)
+    ds = ds + (None,) * (6 - len(ds))                 # sites 4, 5: the two TwoLSTM vectors (seq2vec.py:73-74)
+    q = encode_question(tokens, p, ds[4:6])
     u = q
     att = []
     pooled = None
@@ -291,7 +305,7 @@ def oa_aa(count: np.ndarray, right: np.ndarray):
 def init_params(vq: int, C: int, E: int, Hq: int, Dv: int, A: int, F: int, Hf: int,
                 hops: int = 1, vc: int = 0, Ec: int = 0, seed: int = 0,
                 dtype=torch.float32, mode: str = 'attn', gap_channels: Sequence[int] = (),
-                conv_out: int = 0) -> Dict[str, torch.Tensor]:
+                conv_out: int = 0, two_lstm: bool = False) -> Dict[str, torch.Tensor]:
     """Random parameters with the reference's shapes and state_dict key names
     (model.py:44, 55-58; seq2vec.py:35-38).  nn.Linear / nn.LSTM / nn.Embedding
     default initialisers."""
@@ -309,11 +323,20 @@ def init_params(vq: int, C: int, E: int, Hq: int, Dv: int, A: int, F: int, Hf: i
     emb = torch.randn((vq + 1, E), generator=g, dtype=torch.float64).to(dtype)
     emb[0] = 0
     p['seq2vec.embedding.weight'] = emb
-    k = 1.0 / math.sqrt(Hq)
-    p['seq2vec.rnn.weight_ih_l0'] = uni((4 * Hq, E), k)
-    p['seq2vec.rnn.weight_hh_l0'] = uni((4 * Hq, Hq), k)
-    p['seq2vec.rnn.bias_ih_l0'] = uni((4 * Hq,), k)
-    p['seq2vec.rnn.bias_hh_l0'] = uni((4 * Hq,), k)
+    if two_lstm:                    # seq2vec.py:58-59: hidden = Hq / 2 per layer, outputs concatenated
+        Hh = Hq // 2
+        k = 1.0 / math.sqrt(Hh)
+        for li, nin in enumerate((E, Hh)):
+            p[f'seq2vec.rnn_{li}.weight_ih_l0'] = uni((4 * Hh, nin), k)
+            p[f'seq2vec.rnn_{li}.weight_hh_l0'] = uni((4 * Hh, Hh), k)
+            p[f'seq2vec.rnn_{li}.bias_ih_l0'] = uni((4 * Hh,), k)
+            p[f'seq2vec.rnn_{li}.bias_hh_l0'] = uni((4 * Hh,), k)
+    else:
+        k = 1.0 / math.sqrt(Hq)
+        p['seq2vec.rnn.weight_ih_l0'] = uni((4 * Hq, E), k)
+        p['seq2vec.rnn.weight_hh_l0'] = uni((4 * Hq, Hq), k)
+        p['seq2vec.rnn.bias_ih_l0'] = uni((4 * Hq,), k)
+        p['seq2vec.rnn.bias_hh_l0'] = uni((4 * Hq,), k)
     if mode == 'gap':               # model.py:125-140; linear_v takes the concatenation (model.py:144)
         for k, ck in enumerate(gap_channels, 1):
             linear(f'gap{k}.0', ck, Hq, p)

@@ -167,7 +167,7 @@ def test_question_encoder_against_reference_fixture(golden_dir, dtype):
         ids = torch.from_numpy(z[f'{name}_ids']).cuda()
         B, L = ids.shape
         q = m.encode_question(ids)
-        ws = m._workspace(B, 1, L, 0, ids.device)
+        ws = m._enc_workspace(B, L, ids.device)
         torch.cuda.synchronize()
         assert np.array_equal(ws['len'].cpu().numpy(), z[f'{name}_lengths'].astype(np.int32))
         # packed gather: row offs[t] + j holds the embedding of token t of sorted row j (= original row
@@ -186,6 +186,64 @@ def test_question_encoder_against_reference_fixture(golden_dir, dtype):
             if dtype == torch.float32:
                 assert torch.equal(got, torch.from_numpy(z[f'{name}_emb'])[torch.from_numpy(rows), t])
         assert rel_err(q, torch.from_numpy(z[f'{name}_last'])) <= tol
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_two_lstm_encoder_against_reference_fixture(golden_dir, dtype):
+    """TwoLSTM (seq2vec.py:48-76) against outputs of the reference's own module run along the token axis:
+    tanh on the embeddings, two stacked LSTMs, select_last of each, concatenation."""
+    from vqa_amd.model import VQAAttnModel
+    z = np.load(os.path.join(golden_dir, 'g2b_two_lstm.npz'))
+    Vq1, E = z['embedding'].shape
+    Hh = z['rnn_0.weight_hh_l0'].shape[1]
+    m = VQAAttnModel(['w'] * (Vq1 - 1), ['a'] * 5, None, dtype=dtype, emb_size=E, question_out=2 * Hh, visual_out=32,
+                     attention_dim=16, fusion_in=16, fusion_hidden=8, seq2vec_arch='2-lstm')
+    sd = m.state_dict()
+    sd['seq2vec.embedding.weight'] = torch.from_numpy(z['embedding'])
+    for k in z.files:
+        if k.startswith('rnn_'):
+            sd['seq2vec.' + k] = torch.from_numpy(z[k])
+    m.load_state_dict(sd)
+    m = m.to('cuda').eval()
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    for name in ('main', 'rand'):
+        q = m.encode_question(torch.from_numpy(z[f'{name}_ids']).cuda())
+        assert rel_err(q, torch.from_numpy(z[f'{name}_last'])) <= tol
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_two_lstm_model_forward_backward(dtype):
+    """Whole step with the 2-lstm question encoder, eval and training mode (dropout 0.3 on the two
+    question vectors uses dropout sites 4 and 5)."""
+    from vqa_amd.model import VQAAttnModel
+    kw = dict(MID, Hq=208)
+    p = vqa_ref.init_params(seed=3, two_lstm=True, **kw)
+    m = VQAAttnModel(['w'] * kw['vq'], ['a'] * kw['C'], None, dtype=dtype, emb_size=kw['E'], question_out=kw['Hq'],
+                     visual_out=kw['Dv'], attention_dim=kw['A'], fusion_in=kw['F'], fusion_hidden=kw['Hf'],
+                     seed=1234, seq2vec_arch='2-lstm')
+    m.load_state_dict(p)
+    m = m.to('cuda')
+    b = batch(kw, 21, 25, 14)
+    feats = b['feats'].to(dtype)
+    po = oracle_params_as(p, dtype)
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    for train in (False, True):
+        m.train(train)
+        seeds = [vqa_ref.site_seed(1234, m.drop_step + 1, s) for s in range(6)] if train else None
+        logits_ref, loss_ref, grads_ref = vqa_ref.loss_and_grads(po, feats.float(), b['tokens'], b['answers'], None, 1,
+                                                                 drop_seeds=seeds)
+        _, _, grads64 = vqa_ref.loss_and_grads({k: v.double() for k, v in po.items()}, feats.double(), b['tokens'],
+                                               b['answers'], None, 1, drop_seeds=seeds)
+        logits = m(feats.cuda(), b['tokens'].cuda())
+        assert rel_err(logits, logits_ref) <= tol
+        m.zero_grad()
+        torch.nn.functional.cross_entropy(logits.float(), b['answers'].cuda()).backward()
+        named = dict(m.named_parameters())
+        for k, gref in grads_ref.items():
+            if k.endswith('linear_a.bias'):
+                continue
+            noise = rel_err(gref, grads64[k])
+            assert rel_err(named[k].grad, grads64[k]) <= max(2 * tol, 4 * noise), (k, train)
 
 
 def test_train_step_matches_oracle_adam():

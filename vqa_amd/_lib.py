@@ -25,8 +25,8 @@ _SIGNATURES = {
     'vqa_embedding_gather': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     'vqa_lstm_cell': [_p, _i, _z, _p, _i, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     'vqa_sequence_pack': [_p, _i, _i, _p, _p, _p, _p, _p],
-    'vqa_embedding_gather_packed': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _i, _p],
-    'vqa_lstm_cell_packed': [_p, _i, _z, _p, _i, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p],
+    'vqa_embedding_gather_packed': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _i, _i, _p],
+    'vqa_lstm_cell_packed': [_p, _i, _z, _p, _i, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _i, _p],
     'vqa_caption_pool': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     'vqa_inv_norm': [_p, _p, _l, _i, _i, _i, _p],
     'vqa_grid_mean_splits': [_i, _i, _i, _i],

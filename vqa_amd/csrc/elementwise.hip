@@ -99,7 +99,7 @@ template <typename T>
 __global__ void k_embedding_gather_packed(const int64_t* __restrict__ tok, const T* __restrict__ table,
                                           T* __restrict__ out, int B, int L, int width, int ld_table,
                                           int ld_out, int n_rows, const int* __restrict__ perm,
-                                          const int* __restrict__ offs) {
+                                          const int* __restrict__ offs, int act) {
     const int vec_per_row = width >> 3;
     const long total = (long)offs[L] * vec_per_row;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -112,6 +112,10 @@ __global__ void k_embedding_gather_packed(const int64_t* __restrict__ tok, const
         if (id < 0 || id >= n_rows) id = 0;
         float x[8];
         Vec8<T>::load(table + (size_t)id * ld_table + v * 8, x);
+        if (act == 1) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = Act<T>::tanh_(x[e]);
+        }
         Vec8<T>::store(out + (size_t)prow * ld_out + v * 8, x);
     }
 }
@@ -164,7 +168,8 @@ __global__ void __launch_bounds__(256) k_lstm_cell(const float* __restrict__ sla
                             T* __restrict__ h, int ld_h, const int* __restrict__ len,
                             float* __restrict__ q32, T* __restrict__ qT, int ld_q,
                             int B, int H, int t, int L, const int* __restrict__ perm,
-                            const int* __restrict__ m_t, const int* __restrict__ offs) {
+                            const int* __restrict__ m_t, const int* __restrict__ offs,
+                            T* __restrict__ hs, int ld_hs) {
     // packed mode (perm != null): state rows are in sorted order, only the first m_t[t] are live, their
     // input-projection rows start at row offs[t] of xg and q goes to the original row perm[b]
     const int H4 = H >> 2;
@@ -193,6 +198,7 @@ __global__ void __launch_bounds__(256) k_lstm_cell(const float* __restrict__ sla
         }
         Vec4<float>::store(c + (size_t)b * H + j, cn);
         Vec4<T>::store(h + (size_t)b * ld_h + j, hn);
+        if (hs) Vec4<T>::store(hs + (size_t)(xrow0 + b) * ld_hs + j, hn);     // every step's output, packed rows
         const int ob = perm ? perm[b] : b;
         int last = len[ob] - 1;
         if (last < 0) last += L;               // all-pad row: negative index -> last step
@@ -585,31 +591,33 @@ int vqa_sequence_pack(const int64_t* tokens, int B, int L, int32_t* lengths, int
 
 int vqa_embedding_gather_packed(const int64_t* tokens, const void* table, void* out, int B, int L, int width,
                                 int ld_table, int ld_out, int n_rows, const int32_t* perm, const int32_t* offsets,
-                                int dtype, hipStream_t stream) {
+                                int act, int dtype, hipStream_t stream) {
     VQA_REQUIRE(tokens && table && out && perm && offsets && B >= 0 && L > 0 && n_rows > 0,
                 "vqa_embedding_gather_packed: bad arguments");
     VQA_REQUIRE(width > 0 && width % 8 == 0 && ld_table % 8 == 0 && ld_out % 8 == 0 && width <= ld_table && width <= ld_out,
                 "vqa_embedding_gather_packed: width and leading dimensions must be multiples of 8");
+    VQA_REQUIRE(act == 0 || act == 1, "vqa_embedding_gather_packed: act must be 0 (none) or 1 (tanh)");
     if (B == 0) return 0;
     const long total = (long)B * L * (width / 8);
     DISPATCH_T(dtype, (k_embedding_gather_packed<T><<<grid_for(total, 256), 256, 0, stream>>>(
-        tokens, (const T*)table, (T*)out, B, L, width, ld_table, ld_out, n_rows, perm, offsets)));
+        tokens, (const T*)table, (T*)out, B, L, width, ld_table, ld_out, n_rows, perm, offsets, act)));
     return vqa_check_launch("vqa_embedding_gather_packed");
 }
 
 int vqa_lstm_cell_packed(const float* slabs, int nslab, size_t slab_stride, const void* xg, int ld_xg, float* c,
                          void* h, int ld_h, const int32_t* lengths, float* q_f32, void* q_t, int ld_q,
                          int B, int H, int t, int L, const int32_t* perm, const int32_t* active,
-                         const int32_t* offsets, int dtype, hipStream_t stream) {
+                         const int32_t* offsets, void* hs, int ld_hs, int dtype, hipStream_t stream) {
     VQA_REQUIRE(xg && c && h && lengths && q_f32 && q_t && perm && active && offsets && (nslab == 0 || slabs),
                 "vqa_lstm_cell_packed: null pointer");
     VQA_REQUIRE(B >= 0 && H > 0 && t >= 0 && t < L && ld_xg >= 4 * H && ld_h >= H && ld_q >= H, "vqa_lstm_cell_packed: bad sizes");
     VQA_REQUIRE(H % 4 == 0 && ld_xg % 4 == 0 && ld_h % 4 == 0 && ld_q % 4 == 0 && (slab_stride % 4 == 0 || nslab <= 1),
                 "vqa_lstm_cell_packed: H and leading dimensions must be multiples of 4");
+    VQA_REQUIRE(!hs || (ld_hs >= H && ld_hs % 4 == 0), "vqa_lstm_cell_packed: bad ld_hs");
     if (B == 0) return 0;
     DISPATCH_T(dtype, (k_lstm_cell<T><<<grid_for((long)B * (H / 4), 256), 256, 0, stream>>>(
         slabs, nslab, slab_stride, (const T*)xg, ld_xg, c, (T*)h, ld_h, lengths, q_f32, (T*)q_t, ld_q, B, H, t, L,
-        perm, active, offsets)));
+        perm, active, offsets, (T*)hs, ld_hs)));
     return vqa_check_launch("vqa_lstm_cell_packed");
 }
 
@@ -623,7 +631,7 @@ int vqa_lstm_cell(const float* slabs, int nslab, size_t slab_stride, const void*
     if (B == 0) return 0;
     DISPATCH_T(dtype, (k_lstm_cell<T><<<grid_for((long)B * (H / 4), 256), 256, 0, stream>>>(
         slabs, nslab, slab_stride, (const T*)xg_t, ld_xg, c, (T*)h, ld_h, lengths, q_f32, (T*)q_t, ld_q, B, H, t, L,
-        nullptr, nullptr, nullptr)));
+        nullptr, nullptr, nullptr, (T*)nullptr, 0)));
     return vqa_check_launch("vqa_lstm_cell");
 }
 

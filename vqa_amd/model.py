@@ -51,19 +51,30 @@ def site_seed(base_seed: int, step: int, site: int) -> int:
 
 
 class _Seq2Vec(nn.Module):
-    """Parameter holder with the reference's names (seq2vec.py:27-38): ``embedding``
-    has len(vocab)+1 rows with the pad row 0, ``rnn`` is a single-layer LSTM."""
+    """Parameter holder with the reference's names: ``embedding`` has len(vocab)+1 rows with the pad
+    row 0; arch 'lstm' has ``rnn`` (seq2vec.py:27-38), arch '2-lstm' has ``rnn_0`` / ``rnn_1`` of half
+    the output width each (TwoLSTM, seq2vec.py:48-59)."""
 
-    def __init__(self, n_vocab: int, emb_size: int, hidden_size: int, gen: torch.Generator):
+    def __init__(self, n_vocab: int, emb_size: int, out_size: int, gen: torch.Generator, arch: str = 'lstm'):
         super().__init__()
+        self.arch = arch
         self.embedding = nn.Embedding(n_vocab + 1, emb_size, padding_idx=0)
-        self.rnn = nn.LSTM(input_size=emb_size, hidden_size=hidden_size, num_layers=1)
+        if arch == 'lstm':
+            self.rnn = nn.LSTM(input_size=emb_size, hidden_size=out_size, num_layers=1)
+            self.layers = [self.rnn]
+        elif arch == '2-lstm':
+            self.rnn_0 = nn.LSTM(input_size=emb_size, hidden_size=out_size // 2, num_layers=1)
+            self.rnn_1 = nn.LSTM(input_size=out_size // 2, hidden_size=out_size // 2, num_layers=1)
+            self.layers = [self.rnn_0, self.rnn_1]
+        else:
+            raise NotImplementedError(f"seq2vec arch {arch!r}: 'lstm' and '2-lstm' are built")
         with torch.no_grad():
             self.embedding.weight.copy_(torch.randn(self.embedding.weight.shape, generator=gen))
             self.embedding.weight[0].zero_()
-            k = 1.0 / math.sqrt(hidden_size)
-            for p in self.rnn.parameters():
-                p.copy_((torch.rand(p.shape, generator=gen) * 2 - 1) * k)
+            for rnn in self.layers:
+                k = 1.0 / math.sqrt(rnn.hidden_size)
+                for p in rnn.parameters():
+                    p.copy_((torch.rand(p.shape, generator=gen) * 2 - 1) * k)
 
 
 class _Hop(nn.Module):
@@ -105,7 +116,8 @@ class _VQAHeadModel(nn.Module):
                  question_out: int = QUESTION_OUT, visual_out: int = VISUAL_OUT,
                  attention_dim: int = FUSION_IN, fusion_in: int = FUSION_IN,
                  fusion_hidden: int = FUSION_HIDDEN, hops: int = 1, dropout: float = DROPOUT_F,
-                 caption_vocab: int = 0, caption_dim: int = 384, seed: int = 0, gemm_engine: int = 0):
+                 caption_vocab: int = 0, caption_dim: int = 384, seed: int = 0, gemm_engine: int = 0,
+                 seq2vec_arch: str = 'lstm', seq2vec_dropout: float = 0.3):
         super().__init__()
         self.args = args
         self.vocab_questions = vocab_questions
@@ -128,7 +140,10 @@ class _VQAHeadModel(nn.Module):
             raise ValueError('hops must be >= 1')
 
         gen = torch.Generator().manual_seed(seed)
-        self.seq2vec = _Seq2Vec(len(vocab_questions), emb_size, question_out, gen)
+        if seq2vec_arch == '2-lstm' and question_out % 16:
+            raise ValueError('question_out must be a multiple of 16 for the 2-lstm encoder (two halves of 8-element chunks)')
+        self.seq2vec = _Seq2Vec(len(vocab_questions), emb_size, question_out, gen, seq2vec_arch)
+        self.seq2vec_dropout = float(seq2vec_dropout)      # F.dropout(p=0.3) on each TwoLSTM vector, seq2vec.py:73-74
         for p in self.seq2vec.parameters():          # frozen, as model.py:42-43
             p.requires_grad = False
         self._build_visual(gen)
@@ -242,16 +257,16 @@ class _VQAHeadModel(nn.Module):
         self._shadow_version = self._flat._version
 
     def _refresh_frozen(self, device):
-        """Compute-dtype copies of the frozen question / caption encoder weights:
-        embedding table and W_ih zero-padded to a multiple of 8 columns, b_ih + b_hh."""
-        ps = [self.seq2vec.embedding.weight, self.seq2vec.rnn.weight_ih_l0, self.seq2vec.rnn.weight_hh_l0,
-              self.seq2vec.rnn.bias_ih_l0, self.seq2vec.rnn.bias_hh_l0]
+        """Compute-dtype copies of the frozen question / caption encoder weights: embedding table and
+        every W_ih zero-padded to a multiple of 8 columns, b_ih + b_hh summed, per LSTM layer."""
+        ps = [self.seq2vec.embedding.weight]
+        for rnn in self.seq2vec.layers:
+            ps += [rnn.weight_ih_l0, rnn.weight_hh_l0, rnn.bias_ih_l0, rnn.bias_hh_l0]
         if self.Ec:
             ps.append(self.caption_embedding.weight)
         key = tuple((p.data_ptr(), p._version) for p in ps) + (str(device),)
         if key == self._frozen_key:
             return
-        Ep = _pad8(self.E)
         tdt = self.compute_dtype
 
         def cast_pad(src, ld_dst):
@@ -260,12 +275,14 @@ class _VQAHeadModel(nn.Module):
             call('vqa_cast_pad', ptr(src), src.shape[1], ptr(dst), ld_dst, src.shape[0], src.shape[1], self.dt)
             return dst
 
-        self._emb_t = cast_pad(ps[0], Ep)
-        self._wih_t = cast_pad(ps[1], Ep)
-        self._whh_t = cast_pad(ps[2], self.Hq)
-        self._lstm_bias = (ps[3].detach().float() + ps[4].detach().float()).to(device).contiguous()
+        self._emb_t = cast_pad(ps[0], _pad8(self.E))
+        self._enc_layers = []
+        for rnn in self.seq2vec.layers:
+            self._enc_layers.append((cast_pad(rnn.weight_ih_l0, _pad8(rnn.input_size)),
+                                     cast_pad(rnn.weight_hh_l0, rnn.hidden_size),
+                                     (rnn.bias_ih_l0.detach().float() + rnn.bias_hh_l0.detach().float()).to(device).contiguous()))
         if self.Ec:
-            self._cap_t = cast_pad(ps[5], self.Ec)
+            self._cap_t = cast_pad(ps[-1], self.Ec)
         self._frozen_key = key
 
     # ------------------------------------------------------------------ workspace
@@ -282,10 +299,9 @@ class _VQAHeadModel(nn.Module):
         def z(shape, dt):
             return torch.zeros(shape, dtype=dt, device=device)
 
-        ws = {
-            'len': z((B,), torch.int32), 'perm': z((B,), torch.int32), 'm_t': z((L,), torch.int32),
-            'offs': z((L + 1,), torch.int32), 'x_emb': z((L * B, Ep), tdt), 'xg': z((L * B, 4 * H), tdt),
-            'c': z((B, H), f32), 'h': z((B, H), tdt), 'q32': z((B, H), f32), 'qT': z((B, H), tdt),
+        ws = {}
+        self._encoder_buffers(ws, z, B, L)
+        ws.update({
             'pooled_d': z((B, Dv), tdt), 'q_d': z((B, H), tdt),
             'xv': z((B, F), f32), 'xq': z((B, F), f32), 'x': z((B, F + Ec), tdt),
             'h1t': z((B, Hf), f32), 'h1d': z((B, Hf), tdt), 'logits': z((B, Cp), f32),
@@ -293,7 +309,7 @@ class _VQAHeadModel(nn.Module):
             'dz1': z((B, Hf), tdt), 'dzv': z((B, F), tdt), 'dzq': z((B, F), tdt),
             'd_pooled': z((B, Dv), f32),
             'pred': z((B,), torch.int64),
-        }
+        })
         self._visual_workspace(ws, z, B, geom)
         self._ws[key] = ws
         return ws
@@ -370,38 +386,79 @@ class _VQAHeadModel(nn.Module):
         return self._forward_impl(feats, tokens, captions).clone()
 
     def _drop_seeds(self):
-        if not self.training or self.drop_p <= 0.0:
-            return (0, 0, 0, 0), 0.0
+        """Seeds of the dropout sites of one training forward: 0 visual, 1 question, 2 fused, 3 hidden,
+        4 / 5 the two vectors of the 2-lstm encoder."""
+        if not self.training:
+            return (0,) * 6, 0.0
         self.drop_step += 1
-        return tuple(site_seed(self.base_seed, self.drop_step, s) for s in range(4)), self.drop_p
+        return tuple(site_seed(self.base_seed, self.drop_step, s) for s in range(6)), self.drop_p
 
-    def encode_question(self, tokens: torch.Tensor, ws=None) -> torch.Tensor:
-        """Embedding gather + LSTM + last-valid-step selection -> q (B, Hq) fp32."""
+    def encode_question(self, tokens: torch.Tensor, ws=None, seeds=None) -> torch.Tensor:
+        """Embedding gather + LSTM layer(s) + last-valid-step selection -> q (B, Hq) fp32
+        (seq2vec.py:40-45; with the '2-lstm' encoder seq2vec.py:61-76).  `seeds`: the two dropout seeds
+        of the 2-lstm vectors in training mode."""
         B, L = tokens.shape
         dev = tokens.device
         _lib.bind_stream()
         self._refresh_frozen(dev)
         if ws is None:
-            ws = self._workspace(B, 1, L, 0, dev)
-        Ep, H, dt = _pad8(self.E), self.Hq, self.dt
+            ws = self._enc_workspace(B, L, dev)
+        Ep, Hq, dt = _pad8(self.E), self.Hq, self.dt
+        two = self.seq2vec.arch == '2-lstm'
         # packed sequences: rows sorted by length, so the rows still running at step t are the first
         # m_t[t] and their input projections are rows offs[t].. of xg; padding steps cost nothing
         call('vqa_sequence_pack', ptr(tokens), B, L, ptr(ws['len']), ptr(ws['perm']), ptr(ws['m_t']), ptr(ws['offs']))
         call('vqa_embedding_gather_packed', ptr(tokens), ptr(self._emb_t), ptr(ws['x_emb']), B, L, Ep, Ep, Ep,
-             self._emb_t.shape[0], ptr(ws['perm']), ptr(ws['offs']), dt)
+             self._emb_t.shape[0], ptr(ws['perm']), ptr(ws['offs']), 1 if two else 0, dt)
         total_rows = ws['offs'].data_ptr() + 4 * L
-        call('vqa_gemm_fused_rows', ptr(ws['x_emb']), Ep, 1, ptr(self._wih_t), Ep, 1, ptr(ws['xg']), 4 * H,
-             L * B, 4 * H, Ep, ptr(self._lstm_bias), None, 0, dt, dt, self.gemm_engine, total_rows)
-        for t in range(L):
-            if t == 0:
-                slab, sk, stride = None, 0, 0
-            else:
-                slab, sk, stride = self._gemm_slabs(ws['h'], H, 1, self._whh_t, H, 1, B, 4 * H, H,
-                                                    active_rows=ws['m_t'].data_ptr() + 4 * t)
-            call('vqa_lstm_cell_packed', ptr(slab), sk, stride, ptr(ws['xg']), 4 * H, ptr(ws['c']), ptr(ws['h']), H,
-                 ptr(ws['len']), ptr(ws['q32']), ptr(ws['qT']), H, B, H, t, L, ptr(ws['perm']), ptr(ws['m_t']),
-                 ptr(ws['offs']), dt)
+        x, kin = ws['x_emb'], Ep
+        esz = ws['qT'].element_size()
+        for li, (wih, whh, bias) in enumerate(self._enc_layers):
+            Hh = whh.shape[1]
+            last_layer = li + 1 == len(self._enc_layers)
+            hs = None if last_layer else ws['hs']
+            call('vqa_gemm_fused_rows', ptr(x), kin, 1, ptr(wih), kin, 1, ptr(ws['xg']), 4 * Hh,
+                 L * B, 4 * Hh, kin, ptr(bias), None, 0, dt, dt, self.gemm_engine, total_rows)
+            q32 = ws['q32'].data_ptr() + 4 * li * Hh            # this layer's columns of q
+            qT = ws['qT'].data_ptr() + esz * li * Hh
+            for t in range(L):
+                if t == 0:
+                    slab, sk, stride = None, 0, 0
+                else:
+                    slab, sk, stride = self._gemm_slabs(ws['h'], Hh, 1, whh, Hh, 1, B, 4 * Hh, Hh,
+                                                        active_rows=ws['m_t'].data_ptr() + 4 * t)
+                call('vqa_lstm_cell_packed', ptr(slab), sk, stride, ptr(ws['xg']), 4 * Hh, ptr(ws['c']), ptr(ws['h']), Hh,
+                     ptr(ws['len']), q32, qT, Hq, B, Hh, t, L, ptr(ws['perm']), ptr(ws['m_t']),
+                     ptr(ws['offs']), ptr(hs), Hh, dt)
+            x, kin = hs, Hh
+        if two and self.training and self.seq2vec_dropout > 0.0 and seeds is not None:
+            Hh = Hq // 2
+            for li in range(2):                                  # F.dropout(vec_li, 0.3), seq2vec.py:73-74
+                call('vqa_dropout', ws['q32'].data_ptr() + 4 * li * Hh, Hq, ws['q32'].data_ptr() + 4 * li * Hh, Hq, B, Hh,
+                     seeds[li], self.seq2vec_dropout, _lib.F32)
+                call('vqa_dropout', ws['qT'].data_ptr() + esz * li * Hh, Hq, ws['qT'].data_ptr() + esz * li * Hh, Hq, B, Hh,
+                     seeds[li], self.seq2vec_dropout, dt)
         return ws['q32']
+
+    def _enc_workspace(self, B, L, device):
+        """Question-encoder buffers alone (encode_question called outside a forward)."""
+        key = ('enc', B, L, str(device))
+        ws = self._ws.get(key)
+        if ws is None:
+            ws = {}
+            self._encoder_buffers(ws, lambda shape, dt: torch.zeros(shape, dtype=dt, device=device), B, L)
+            self._ws[key] = ws
+        return ws
+
+    def _encoder_buffers(self, ws, z, B, L):
+        tdt, f32 = self.compute_dtype, torch.float32
+        Ep, H = _pad8(self.E), self.Hq
+        Hh = max(rnn.hidden_size for rnn in self.seq2vec.layers)
+        ws.update({'len': z((B,), torch.int32), 'perm': z((B,), torch.int32), 'm_t': z((L,), torch.int32),
+                   'offs': z((L + 1,), torch.int32), 'x_emb': z((L * B, Ep), tdt), 'xg': z((L * B, 4 * Hh), tdt),
+                   'c': z((B, Hh), f32), 'h': z((B, Hh), tdt), 'q32': z((B, H), f32), 'qT': z((B, H), tdt)})
+        if len(self.seq2vec.layers) > 1:
+            ws['hs'] = z((L * B, Hh), tdt)
 
     def _forward_impl(self, feats, tokens, captions):
         B, L = tokens.shape
@@ -416,7 +473,7 @@ class _VQAHeadModel(nn.Module):
 
         # parameter-independent prologue first: a gradient bucket still being all-reduced from the
         # previous train_step (and its Adam update) is only needed from here on
-        self.encode_question(tokens, ws)
+        self.encode_question(tokens, ws, seeds[4:6])
         self._visual_prologue(ws, feats, B)
         self._finish_pending()
         self._refresh_shadow()
