@@ -73,7 +73,8 @@ int vqa_sequence_pack(const int64_t* tokens, int B, int L, int32_t* lengths, int
  * 1 tanh (TwoLSTM applies tanh to the embeddings)                  seq2vec.py:42, 63-64 */
 int vqa_embedding_gather_packed(const int64_t* tokens, const void* table, void* out, int B, int L, int width,
                                 int ld_table, int ld_out, int n_rows, const int32_t* perm, const int32_t* offsets,
-                                int act, int dtype, hipStream_t stream);
+                                int act, int32_t* packed_tokens, int dtype, hipStream_t stream);
+/* (packed_tokens, optional: packed_tokens[offsets[t] + j] = the token id gathered into that row) */
 /* vqa_lstm_cell on packed sequences: state rows c, h and the slabs are in sorted order, only rows
  * j < active[t] are updated, the input projection of row j is row offsets[t] + j of xg, and the
  * selected output goes to q[perm[j]].  hs (optional) receives every step's output at the packed
@@ -81,7 +82,26 @@ int vqa_embedding_gather_packed(const int64_t* tokens, const void* table, void* 
 int vqa_lstm_cell_packed(const float* slabs, int nslab, size_t slab_stride, const void* xg, int ld_xg, float* c,
                          void* h, int ld_h, const int32_t* lengths, float* q_f32, void* q_t, int ld_q,
                          int B, int H, int t, int L, const int32_t* perm, const int32_t* active,
-                         const int32_t* offsets, void* hs, int ld_hs, int dtype, hipStream_t stream);
+                         const int32_t* offsets, void* hs, int ld_hs, void* gates_out, float* c_out, int dtype,
+                         hipStream_t stream);
+/* (gates_out (packed rows x 4H, activated i, f, g, o) and c_out (packed rows x H, fp32), optional and
+ *  together: the state saved for backward through time) */
+
+/* Backward through LSTM step t on packed sequences (a trainable question encoder; the reference
+ * freezes it, model.py:42-43, so this has no counterpart there beyond autograd of seq2vec.py:43):
+ * slabs = dG_{t+1} W_hh partial sums (rows running at t+1), dq (B, ld_dq) in original row order is the
+ * gradient of the selected outputs, dh_ext (optional, packed rows x H fp32) a gradient arriving at
+ * every step's output; writes dG and hprev (h_{t-1}) at packed row offsets[t] + j, dG also at row j of
+ * dG_state (B x 4H, the operand of the next recurrent product), updates dc_state. */
+int vqa_lstm_cell_bwd_packed(const float* slabs, int nslab, size_t slab_stride, const float* dq, int ld_dq,
+                             const float* dh_ext, const void* gates, const float* cs, const void* hs, float* dc_state,
+                             void* dG, void* dG_state, void* hprev, const int32_t* lengths, const int32_t* perm, const int32_t* active,
+                             const int32_t* offsets, int B, int H, int t, int L, int dtype, hipStream_t stream);
+/* dE[v, :] = sum over packed rows p with packed_tokens[p] == v, in ascending p, of (sum_s slabs[s][p, :]) *
+ * (1 - x_act[p, :]^2 if x_act); dE[0, :] = 0 (padding_idx, seq2vec.py:35-37).  No float atomics. */
+int vqa_embedding_grad(const float* slabs, int nslab, size_t slab_stride, int ld_dx, const int32_t* packed_tokens,
+                       const int32_t* total_rows, const void* x_act, int ld_x, float* dE, int V, int E, int dtype,
+                       hipStream_t stream);
 
 /* out[b, col0:col0+Ec] = l2norm(sum_t table[cap[b,t]] * (cap != 0) / max(#nonzero, 1e-9))
  *                      model.py:1571-1574 (mean_pooling), 1678 (F.normalize), 1734 (cat) */
@@ -148,10 +168,11 @@ int vqa_gemm_slabs(const void* A, int lda, int a_kmajor, const void* B, int ldb,
                    hipStream_t stream);
 /* The same two products restricted to the first *active_rows rows of the output (a device-side
  * count read by the kernel: workgroups whose first row is past it exit; rows past it inside a
- * started tile may or may not be written).  active_rows may be NULL. */
+ * started tile may or may not be written) and, for the slab form, to the first *active_k terms of
+ * the contraction (exact: later k contribute nothing).  Either pointer may be NULL. */
 int vqa_gemm_slabs_rows(const void* A, int lda, int a_kmajor, const void* B, int ldb, int b_kmajor, float* slabs,
                         size_t slab_stride, int ld_slab, int M, int N, int K, int splitk, int dtype, int engine,
-                        const int32_t* active_rows, hipStream_t stream);
+                        const int32_t* active_rows, const int32_t* active_k, hipStream_t stream);
 int vqa_gemm_fused_rows(const void* A, int lda, int a_kmajor, const void* B, int ldb, int b_kmajor, void* C, int ldc,
                         int M, int N, int K, const float* bias, const float* row_scale, int act, int out_dtype,
                         int dtype, int engine, const int32_t* active_rows, hipStream_t stream);
@@ -186,6 +207,8 @@ int vqa_tanh_dropout_bwd(const float* slabs, int nslab, size_t slab_stride, cons
 
 /* out[n] = sum_m X[m,n] (bias gradients), fixed summation order */
 int vqa_colsum(const void* X, int ld, float* out, int M, int N, int dtype, hipStream_t stream);
+/* the same over the first *rows rows (a device-side count) */
+int vqa_colsum_rows(const void* X, int ld, float* out, const int32_t* rows, int N, int dtype, hipStream_t stream);
 /* dst[m,0:N] = (dtype) src[m,0:N]; dst[m,N:ld_dst] = 0 */
 int vqa_cast_pad(const float* src, int ld_src, void* dst, int ld_dst, int M, int N, int dtype, hipStream_t stream);
 

@@ -92,8 +92,9 @@ def select_last(x: torch.Tensor, lengths: torch.Tensor) -> torch.Tensor:
 
 
 def embedding_gather(tokens: torch.Tensor, table: torch.Tensor) -> torch.Tensor:
-    """nn.Embedding lookup (seq2vec.py:35-37, 42); row 0 is the pad row."""
-    return table[tokens.long()]
+    """nn.Embedding lookup with padding_idx=0 (seq2vec.py:35-37, 42): row 0 is the pad row and
+    receives no gradient."""
+    return torch.nn.functional.embedding(tokens.long(), table, padding_idx=0)
 
 
 def lstm_time_major(e: torch.Tensor, w_ih, w_hh, b_ih, b_hh) -> torch.Tensor:
@@ -366,15 +367,17 @@ def init_params(vq: int, C: int, E: int, Hq: int, Dv: int, A: int, F: int, Hf: i
 FROZEN_PREFIXES = ('seq2vec.', 'caption_embedding.')
 
 
-def trainable_names(p: Dict[str, torch.Tensor]) -> List[str]:
-    """The question encoder is frozen (model.py:42-43); so is the caption
+def trainable_names(p: Dict[str, torch.Tensor], train_encoder: bool = False) -> List[str]:
+    """The question encoder is frozen (model.py:42-43) unless train_encoder; so is the caption
     encoder (it runs under no_grad, model.py:1675-1676)."""
-    return [k for k in p if not k.startswith(FROZEN_PREFIXES)]
+    frozen = ('caption_embedding.',) if train_encoder else FROZEN_PREFIXES
+    return [k for k in p if not k.startswith(frozen)]
 
 
-def loss_and_grads(p, feats, tokens, answers, captions=None, hops=1, drop_seeds=None, drop_p=0.5, mode='attn'):
+def loss_and_grads(p, feats, tokens, answers, captions=None, hops=1, drop_seeds=None, drop_p=0.5, mode='attn',
+                   train_encoder=False):
     """One fwd + loss + bwd of the step (train.py:200-203) through autograd."""
-    names = trainable_names(p)
+    names = trainable_names(p, train_encoder)
     q = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in p.items()}
     logits = forward(q, feats, tokens, captions, hops, drop_seeds, drop_p, mode=mode)
     loss = cross_entropy(logits, answers)

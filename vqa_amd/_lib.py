@@ -25,8 +25,11 @@ _SIGNATURES = {
     'vqa_embedding_gather': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     'vqa_lstm_cell': [_p, _i, _z, _p, _i, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     'vqa_sequence_pack': [_p, _i, _i, _p, _p, _p, _p, _p],
-    'vqa_embedding_gather_packed': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _i, _i, _p],
-    'vqa_lstm_cell_packed': [_p, _i, _z, _p, _i, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _i, _p],
+    'vqa_embedding_gather_packed': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _i, _p, _i, _p],
+    'vqa_lstm_cell_packed': [_p, _i, _z, _p, _i, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p, _p, _i, _p],
+    'vqa_lstm_cell_bwd_packed': [_p, _i, _z, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    'vqa_embedding_grad': [_p, _i, _z, _i, _p, _p, _p, _i, _p, _i, _i, _i, _p],
+    'vqa_colsum_rows': [_p, _i, _p, _p, _i, _i, _p],
     'vqa_caption_pool': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     'vqa_inv_norm': [_p, _p, _l, _i, _i, _i, _p],
     'vqa_grid_mean_splits': [_i, _i, _i, _i],
@@ -40,7 +43,7 @@ _SIGNATURES = {
     'vqa_attn_bwd': [_p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _i, _p, _i, _p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _p],
     'vqa_gemm_splitk_hint': [_i, _i, _i, _i, _i],
     'vqa_gemm_slabs': [_p, _i, _i, _p, _i, _i, _p, _z, _i, _i, _i, _i, _i, _i, _i, _p],
-    'vqa_gemm_slabs_rows': [_p, _i, _i, _p, _i, _i, _p, _z, _i, _i, _i, _i, _i, _i, _i, _p, _p],
+    'vqa_gemm_slabs_rows': [_p, _i, _i, _p, _i, _i, _p, _z, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p],
     'vqa_gemm_fused_rows': [_p, _i, _i, _p, _i, _i, _p, _i, _i, _i, _i, _p, _p, _i, _i, _i, _i, _p, _p],
     'vqa_gemm_fused': [_p, _i, _i, _p, _i, _i, _p, _i, _i, _i, _i, _p, _p, _i, _i, _i, _i, _p],
     'vqa_epilogue': [_p, _i, _z, _i, _i, _p, _p, _p, _i, _i, _p, _i, _p, _i, _i, _u, _f, _p],

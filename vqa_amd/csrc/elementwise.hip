@@ -99,7 +99,7 @@ template <typename T>
 __global__ void k_embedding_gather_packed(const int64_t* __restrict__ tok, const T* __restrict__ table,
                                           T* __restrict__ out, int B, int L, int width, int ld_table,
                                           int ld_out, int n_rows, const int* __restrict__ perm,
-                                          const int* __restrict__ offs, int act) {
+                                          const int* __restrict__ offs, int act, int* __restrict__ ptok) {
     const int vec_per_row = width >> 3;
     const long total = (long)offs[L] * vec_per_row;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -110,6 +110,7 @@ __global__ void k_embedding_gather_packed(const int64_t* __restrict__ tok, const
         const int b = perm[prow - offs[t]];
         int64_t id = tok[(size_t)b * L + t];
         if (id < 0 || id >= n_rows) id = 0;
+        if (ptok && v == 0) ptok[prow] = (int)id;
         float x[8];
         Vec8<T>::load(table + (size_t)id * ld_table + v * 8, x);
         if (act == 1) {
@@ -169,7 +170,7 @@ __global__ void __launch_bounds__(256) k_lstm_cell(const float* __restrict__ sla
                             float* __restrict__ q32, T* __restrict__ qT, int ld_q,
                             int B, int H, int t, int L, const int* __restrict__ perm,
                             const int* __restrict__ m_t, const int* __restrict__ offs,
-                            T* __restrict__ hs, int ld_hs) {
+                            T* __restrict__ hs, int ld_hs, T* __restrict__ gates_out, float* __restrict__ cs_out) {
     // packed mode (perm != null): state rows are in sorted order, only the first m_t[t] are live, their
     // input-projection rows start at row offs[t] of xg and q goes to the original row perm[b]
     const int H4 = H >> 2;
@@ -195,6 +196,12 @@ __global__ void __launch_bounds__(256) k_lstm_cell(const float* __restrict__ sla
             const float gg = Act<T>::tanh_(g[2][e]), og = Act<T>::sigm_(g[3][e]);
             cn[e] = fg * cprev[e] + ig * gg;
             hn[e] = og * Act<T>::tanh_(cn[e]);
+            g[0][e] = ig; g[1][e] = fg; g[2][e] = gg; g[3][e] = og;
+        }
+        if (gates_out) {                       // saved for backward through time, packed rows
+#pragma unroll
+            for (int k = 0; k < 4; ++k) Vec4<T>::store(gates_out + (size_t)(xrow0 + b) * 4 * H + k * H + j, g[k]);
+            Vec4<float>::store(cs_out + (size_t)(xrow0 + b) * H + j, cn);
         }
         Vec4<float>::store(c + (size_t)b * H + j, cn);
         Vec4<T>::store(h + (size_t)b * ld_h + j, hn);
@@ -543,6 +550,132 @@ __global__ void __launch_bounds__(256) k_adam(float* __restrict__ p, const float
     }
 }
 
+// ---------------------------------------------------------------------------
+// backward through one LSTM time step on packed sequences (rows j < m_t[t], sorted order)
+//   dh   = [row j also runs at t+1] sum_s slab[s][j]  (= dG_{t+1} W_hh)  + [t is row j's last step] dq[perm[j]]
+//          + dh_ext[offs[t] + j]                       (gradient arriving from a stacked layer, optional)
+//   dc   = [runs at t+1] dc_state[j] + dh o (1 - tanh(c_t)^2)
+//   dG   = (dc g i(1-i), dc c_{t-1} f(1-f), dc i (1-g^2), dh tanh(c_t) o(1-o))   -> packed row offs[t] + j
+//   dc_state[j] = dc f;  hprev[offs[t] + j] = h_{t-1}[j]  (0 at t = 0): the operand of dW_hh = dG^T hprev
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) k_lstm_cell_bwd(const float* __restrict__ slabs, int nslab, size_t slab_stride,
+                                const float* __restrict__ dq, int ld_dq, const float* __restrict__ dh_ext,
+                                const T* __restrict__ gates, const float* __restrict__ cs, const T* __restrict__ hs,
+                                float* __restrict__ dc_state, T* __restrict__ dG, T* __restrict__ dgs,
+                                T* __restrict__ hprev, const int* __restrict__ len, const int* __restrict__ perm,
+                                const int* __restrict__ m_t, const int* __restrict__ offs, int H, int t, int L) {
+    const int H4 = H >> 2;
+    const int rows = m_t[t];
+    const int rows_next = t + 1 < L ? m_t[t + 1] : 0;
+    const long r0 = offs[t], rp = t > 0 ? offs[t - 1] : 0;
+    const long total = (long)rows * H4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / H4), j = (int)(i % H4) * 4;
+        const bool runs_next = b < rows_next;
+        f32x4 dh = f32x4{0.f, 0.f, 0.f, 0.f}, dc = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (runs_next) {
+            for (int s = 0; s < nslab; ++s) dh += Vec4<float>::load(slabs + s * slab_stride + (size_t)b * H + j);
+            dc = Vec4<float>::load(dc_state + (size_t)b * H + j);
+        }
+        const int ob = perm[b];
+        int last = len[ob] - 1;
+        if (last < 0) last += L;
+        if (last == t) dh += Vec4<float>::load(dq + (size_t)ob * ld_dq + j);
+        if (dh_ext) dh += Vec4<float>::load(dh_ext + (size_t)(r0 + b) * H + j);
+        const T* gr = gates + (size_t)(r0 + b) * 4 * H + j;
+        const f32x4 ig = Vec4<T>::load(gr), fg = Vec4<T>::load(gr + H), gg = Vec4<T>::load(gr + 2 * H), og = Vec4<T>::load(gr + 3 * H);
+        const f32x4 c = Vec4<float>::load(cs + (size_t)(r0 + b) * H + j);
+        f32x4 cprev = f32x4{0.f, 0.f, 0.f, 0.f}, hp = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (t > 0) {
+            cprev = Vec4<float>::load(cs + (size_t)(rp + b) * H + j);
+            hp = Vec4<T>::load(hs + (size_t)(rp + b) * H + j);
+        }
+        f32x4 di, df, dg, dout, dcp;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float tc = Act<T>::tanh_(c[e]);
+            const float dct = dc[e] + dh[e] * og[e] * (1.0f - tc * tc);
+            dout[e] = dh[e] * tc * og[e] * (1.0f - og[e]);
+            di[e] = dct * gg[e] * ig[e] * (1.0f - ig[e]);
+            df[e] = dct * cprev[e] * fg[e] * (1.0f - fg[e]);
+            dg[e] = dct * ig[e] * (1.0f - gg[e] * gg[e]);
+            dcp[e] = dct * fg[e];
+        }
+        Vec4<float>::store(dc_state + (size_t)b * H + j, dcp);
+        T* go = dG + (size_t)(r0 + b) * 4 * H + j;
+        Vec4<T>::store(go, di); Vec4<T>::store(go + H, df); Vec4<T>::store(go + 2 * H, dg); Vec4<T>::store(go + 3 * H, dout);
+        T* gs = dgs + (size_t)b * 4 * H + j;      // the same row in sorted (unpacked) order: operand of the next recurrent product
+        Vec4<T>::store(gs, di); Vec4<T>::store(gs + H, df); Vec4<T>::store(gs + 2 * H, dg); Vec4<T>::store(gs + 3 * H, dout);
+        Vec4<T>::store(hprev + (size_t)(r0 + b) * H + j, hp);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// embedding gradient without float atomics: one wave per table row v scans the packed token list
+// and adds, in ascending packed-row order, the rows of dX = sum_s slab[s] whose token is v.
+// x_act (optional): the tanh-activated embeddings the layer consumed; dX is then multiplied by
+// 1 - x^2.  The pad row 0 gets a zero gradient (padding_idx).  E <= 1024.
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) k_embedding_grad(const float* __restrict__ slabs, int nslab, size_t slab_stride,
+                                 int ld_dx, const int* __restrict__ ptok, const int* __restrict__ total_rows,
+                                 const T* __restrict__ x_act, int ld_x, float* __restrict__ dE, int V, int E) {
+    const int lane = threadIdx.x & 63;
+    const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (v >= V) return;
+    float acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const int total = *total_rows;
+    if (v != 0) {
+        for (int base = 0; base < total; base += 64) {
+            const int p = base + lane;
+            unsigned long long mask = __ballot(p < total && ptok[p] == v);
+            while (mask) {
+                const int row = base + __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int e = lane + 64 * i;
+                    if (e < E) {
+                        float d = 0.f;
+                        for (int s = 0; s < nslab; ++s) d += slabs[s * slab_stride + (size_t)row * ld_dx + e];
+                        if (x_act) { const float x = to_f32<T>(x_act[(size_t)row * ld_x + e]); d *= 1.0f - x * x; }
+                        acc[i] += d;
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int e = lane + 64 * i;
+        if (e < E) dE[(size_t)v * E + e] = acc[i];
+    }
+}
+
+// column sums over the first *rows rows (a device-side count); otherwise as k_colsum
+template <typename T>
+__global__ void __launch_bounds__(256) k_colsum_rows(const T* __restrict__ X, int ld, float* __restrict__ out,
+                                                     const int* __restrict__ rows, int N) {
+    __shared__ float part[8][33];
+    const int cx = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int n = blockIdx.x * 32 + cx;
+    const int M = *rows;
+    float s0 = 0.f;
+    if (n < N)
+        for (int m = rg; m < M; m += 8) s0 += to_f32<T>(X[(size_t)m * ld + n]);
+    part[rg][cx] = s0;
+    __syncthreads();
+    if (rg == 0 && n < N) {
+        float s = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) s += part[g][cx];
+        out[n] = s;
+    }
+}
+
 // ===========================================================================
 // C ABI
 // ===========================================================================
@@ -591,7 +724,7 @@ int vqa_sequence_pack(const int64_t* tokens, int B, int L, int32_t* lengths, int
 
 int vqa_embedding_gather_packed(const int64_t* tokens, const void* table, void* out, int B, int L, int width,
                                 int ld_table, int ld_out, int n_rows, const int32_t* perm, const int32_t* offsets,
-                                int act, int dtype, hipStream_t stream) {
+                                int act, int32_t* packed_tokens, int dtype, hipStream_t stream) {
     VQA_REQUIRE(tokens && table && out && perm && offsets && B >= 0 && L > 0 && n_rows > 0,
                 "vqa_embedding_gather_packed: bad arguments");
     VQA_REQUIRE(width > 0 && width % 8 == 0 && ld_table % 8 == 0 && ld_out % 8 == 0 && width <= ld_table && width <= ld_out,
@@ -600,24 +733,26 @@ int vqa_embedding_gather_packed(const int64_t* tokens, const void* table, void* 
     if (B == 0) return 0;
     const long total = (long)B * L * (width / 8);
     DISPATCH_T(dtype, (k_embedding_gather_packed<T><<<grid_for(total, 256), 256, 0, stream>>>(
-        tokens, (const T*)table, (T*)out, B, L, width, ld_table, ld_out, n_rows, perm, offsets, act)));
+        tokens, (const T*)table, (T*)out, B, L, width, ld_table, ld_out, n_rows, perm, offsets, act, packed_tokens)));
     return vqa_check_launch("vqa_embedding_gather_packed");
 }
 
 int vqa_lstm_cell_packed(const float* slabs, int nslab, size_t slab_stride, const void* xg, int ld_xg, float* c,
                          void* h, int ld_h, const int32_t* lengths, float* q_f32, void* q_t, int ld_q,
                          int B, int H, int t, int L, const int32_t* perm, const int32_t* active,
-                         const int32_t* offsets, void* hs, int ld_hs, int dtype, hipStream_t stream) {
+                         const int32_t* offsets, void* hs, int ld_hs, void* gates_out, float* c_out, int dtype,
+                         hipStream_t stream) {
     VQA_REQUIRE(xg && c && h && lengths && q_f32 && q_t && perm && active && offsets && (nslab == 0 || slabs),
                 "vqa_lstm_cell_packed: null pointer");
     VQA_REQUIRE(B >= 0 && H > 0 && t >= 0 && t < L && ld_xg >= 4 * H && ld_h >= H && ld_q >= H, "vqa_lstm_cell_packed: bad sizes");
     VQA_REQUIRE(H % 4 == 0 && ld_xg % 4 == 0 && ld_h % 4 == 0 && ld_q % 4 == 0 && (slab_stride % 4 == 0 || nslab <= 1),
                 "vqa_lstm_cell_packed: H and leading dimensions must be multiples of 4");
     VQA_REQUIRE(!hs || (ld_hs >= H && ld_hs % 4 == 0), "vqa_lstm_cell_packed: bad ld_hs");
+    VQA_REQUIRE((gates_out == nullptr) == (c_out == nullptr), "vqa_lstm_cell_packed: gates_out and c_out go together");
     if (B == 0) return 0;
     DISPATCH_T(dtype, (k_lstm_cell<T><<<grid_for((long)B * (H / 4), 256), 256, 0, stream>>>(
         slabs, nslab, slab_stride, (const T*)xg, ld_xg, c, (T*)h, ld_h, lengths, q_f32, (T*)q_t, ld_q, B, H, t, L,
-        perm, active, offsets, (T*)hs, ld_hs)));
+        perm, active, offsets, (T*)hs, ld_hs, (T*)gates_out, c_out)));
     return vqa_check_launch("vqa_lstm_cell_packed");
 }
 
@@ -631,7 +766,7 @@ int vqa_lstm_cell(const float* slabs, int nslab, size_t slab_stride, const void*
     if (B == 0) return 0;
     DISPATCH_T(dtype, (k_lstm_cell<T><<<grid_for((long)B * (H / 4), 256), 256, 0, stream>>>(
         slabs, nslab, slab_stride, (const T*)xg_t, ld_xg, c, (T*)h, ld_h, lengths, q_f32, (T*)q_t, ld_q, B, H, t, L,
-        nullptr, nullptr, nullptr, (T*)nullptr, 0)));
+        nullptr, nullptr, nullptr, (T*)nullptr, 0, (T*)nullptr, nullptr)));
     return vqa_check_launch("vqa_lstm_cell");
 }
 
@@ -723,6 +858,39 @@ int vqa_colsum(const void* X, int ld, float* out, int M, int N, int dtype, hipSt
     VQA_REQUIRE(X && out && M >= 0 && N > 0 && ld >= N, "vqa_colsum: bad arguments");
     DISPATCH_T(dtype, (k_colsum<T><<<(N + 31) / 32, 256, 0, stream>>>((const T*)X, ld, out, M, N)));
     return vqa_check_launch("vqa_colsum");
+}
+
+int vqa_colsum_rows(const void* X, int ld, float* out, const int32_t* rows, int N, int dtype, hipStream_t stream) {
+    VQA_REQUIRE(X && out && rows && N > 0 && ld >= N, "vqa_colsum_rows: bad arguments");
+    DISPATCH_T(dtype, (k_colsum_rows<T><<<(N + 31) / 32, 256, 0, stream>>>((const T*)X, ld, out, rows, N)));
+    return vqa_check_launch("vqa_colsum_rows");
+}
+
+int vqa_lstm_cell_bwd_packed(const float* slabs, int nslab, size_t slab_stride, const float* dq, int ld_dq,
+                             const float* dh_ext, const void* gates, const float* cs, const void* hs, float* dc_state,
+                             void* dG, void* dG_state, void* hprev, const int32_t* lengths, const int32_t* perm, const int32_t* active,
+                             const int32_t* offsets, int B, int H, int t, int L, int dtype, hipStream_t stream) {
+    VQA_REQUIRE(dq && gates && cs && hs && dc_state && dG && dG_state && hprev && lengths && perm && active && offsets &&
+                (nslab == 0 || slabs), "vqa_lstm_cell_bwd_packed: null pointer");
+    VQA_REQUIRE(B >= 0 && H > 0 && H % 4 == 0 && t >= 0 && t < L && ld_dq >= H && ld_dq % 4 == 0 &&
+                (slab_stride % 4 == 0 || nslab <= 1), "vqa_lstm_cell_bwd_packed: bad sizes");
+    VQA_REQUIRE(t + 1 == L || nslab >= 1, "vqa_lstm_cell_bwd_packed: steps before the last need the recurrent slabs");
+    if (B == 0) return 0;
+    DISPATCH_T(dtype, (k_lstm_cell_bwd<T><<<grid_for((long)B * (H / 4), 256), 256, 0, stream>>>(
+        slabs, nslab, slab_stride, dq, ld_dq, dh_ext, (const T*)gates, cs, (const T*)hs, dc_state, (T*)dG, (T*)dG_state, (T*)hprev,
+        lengths, perm, active, offsets, H, t, L)));
+    return vqa_check_launch("vqa_lstm_cell_bwd_packed");
+}
+
+int vqa_embedding_grad(const float* slabs, int nslab, size_t slab_stride, int ld_dx, const int32_t* packed_tokens,
+                       const int32_t* total_rows, const void* x_act, int ld_x, float* dE, int V, int E, int dtype,
+                       hipStream_t stream) {
+    VQA_REQUIRE(slabs && nslab >= 1 && packed_tokens && total_rows && dE && V > 0 && E > 0 && E <= 1024 && ld_dx >= E,
+                "vqa_embedding_grad: bad arguments (E <= 1024)");
+    VQA_REQUIRE(!x_act || ld_x >= E, "vqa_embedding_grad: bad ld_x");
+    DISPATCH_T(dtype, (k_embedding_grad<T><<<(V + 3) / 4, 256, 0, stream>>>(
+        slabs, nslab, slab_stride, ld_dx, packed_tokens, total_rows, (const T*)x_act, ld_x, dE, V, E)));
+    return vqa_check_launch("vqa_embedding_grad");
 }
 
 int vqa_cast_pad(const float* src, int ld_src, void* dst, int ld_dst, int M, int N, int dtype, hipStream_t stream) {

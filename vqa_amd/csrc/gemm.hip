@@ -32,6 +32,8 @@ struct Epi {
     void* out; int ld; int out_bf16; size_t split_stride;
     const float* bias; const float* row_scale; int act;
     const int* m_limit;        // optional device-side row count: row tiles starting at or past *m_limit are not computed
+    const int* k_limit;        // optional device-side contraction length: only k < *k_limit contributes
+    __device__ __forceinline__ int kcap(int K) const { return k_limit ? min(K, *k_limit) : K; }
     __device__ __forceinline__ float value(float v, float rs, float b) const {
         v = v * rs + b;
         if (act == 1) v = out_bf16 ? fast_tanh(v) : tanhf(v);
@@ -290,7 +292,7 @@ k_gemm_bf16(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B,
     const int split = L / tiles, ti = L % tiles;
     const int m0 = (ti / tiles_n) * BM, n0 = (ti % tiles_n) * BN;
     const int kbeg = split * k_per_split;
-    const int kend = min(K, kbeg + k_per_split);
+    const int kend = min(epi.kcap(K), kbeg + k_per_split);
     const int nk = kend > kbeg ? (kend - kbeg + GEMM_BK - 1) / GEMM_BK : 0;    // an empty split stores zeros
 
     f32x4 acc[MT][NT];
@@ -399,7 +401,7 @@ k_gemm_bf16_w8(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__
     const int split = L / tiles, ti = L % tiles;
     const int m0 = (ti / tiles_n) * BM, n0 = (ti % tiles_n) * BN;
     const int kbeg = split * k_per_split;
-    const int kend = min(K, kbeg + k_per_split);
+    const int kend = min(epi.kcap(K), kbeg + k_per_split);
     const int nk = kend > kbeg ? (kend - kbeg + GEMM_BK - 1) / GEMM_BK : 0;
     const int nfull = kend > kbeg ? (kend - kbeg) / GEMM_BK : 0;      // tiles [0, nfull) come by DMA
 
@@ -522,7 +524,7 @@ k_gemm_bf16_r10(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict_
     const int split = L / tiles, ti = L % tiles;
     const int m0 = (ti / tiles_n) * BM, n0 = (ti % tiles_n) * BN;
     const int kbeg = split * k_per_split;
-    const int kend = min(K, kbeg + k_per_split);
+    const int kend = min(epi.kcap(K), kbeg + k_per_split);
     const int nk = kend > kbeg ? (kend - kbeg + GEMM_BK - 1) / GEMM_BK : 0;
     const int nfull = kend > kbeg ? (kend - kbeg) / GEMM_BK : 0;      // tiles [0, nfull) come by DMA
 
@@ -631,7 +633,7 @@ k_gemm_valu(const T* __restrict__ A, int lda, const T* __restrict__ B, int ldb, 
     if (L < 0) return;
     const int split = L / tiles, ti = L % tiles;
     const int m0 = (ti / tiles_n) * 64, n0 = (ti % tiles_n) * 64;
-    const int kbeg = split * k_per_split, kend = min(K, kbeg + k_per_split);
+    const int kbeg = split * k_per_split, kend = min(epi.kcap(K), kbeg + k_per_split);
     float acc[4][4] = {};
     for (int k0 = kbeg; k0 < kend; k0 += 16) {
 #pragma unroll
@@ -797,11 +799,11 @@ int vqa_gemm_splitk_hint(int M, int N, int K, int a_kmajor, int b_kmajor) {
 
 int vqa_gemm_slabs_rows(const void* A, int lda, int a_kmajor, const void* B, int ldb, int b_kmajor, float* slabs,
                         size_t slab_stride, int ld_slab, int M, int N, int K, int splitk, int dtype, int engine,
-                        const int32_t* active_rows, hipStream_t stream) {
+                        const int32_t* active_rows, const int32_t* active_k, hipStream_t stream) {
     if (int rc = gemm_check(A, lda, a_kmajor, B, ldb, b_kmajor, M, N, K, dtype, engine)) return rc;
     VQA_REQUIRE(slabs && splitk >= 1 && splitk <= 64 && ld_slab >= N, "vqa_gemm_slabs: bad slab arguments");
     VQA_REQUIRE(splitk == 1 || slab_stride >= (size_t)M * ld_slab, "vqa_gemm_slabs: slab_stride too small");
-    Epi epi{slabs, ld_slab, 0, slab_stride, nullptr, nullptr, 0, active_rows};
+    Epi epi{slabs, ld_slab, 0, slab_stride, nullptr, nullptr, 0, active_rows, active_k};
     if (dtype == VQA_BF16 && engine != 1) launch_bf16(A, lda, a_kmajor, B, ldb, b_kmajor, M, N, K, splitk, engine, epi, stream);
     else if (dtype == VQA_BF16) launch_valu<bf16_t>(A, lda, a_kmajor, B, ldb, b_kmajor, M, N, K, splitk, epi, stream);
     else launch_valu<float>(A, lda, a_kmajor, B, ldb, b_kmajor, M, N, K, splitk, epi, stream);
@@ -812,7 +814,7 @@ int vqa_gemm_slabs(const void* A, int lda, int a_kmajor, const void* B, int ldb,
                    size_t slab_stride, int ld_slab, int M, int N, int K, int splitk, int dtype, int engine,
                    hipStream_t stream) {
     return vqa_gemm_slabs_rows(A, lda, a_kmajor, B, ldb, b_kmajor, slabs, slab_stride, ld_slab, M, N, K, splitk, dtype,
-                               engine, nullptr, stream);
+                               engine, nullptr, nullptr, stream);
 }
 
 int vqa_gemm_fused_rows(const void* A, int lda, int a_kmajor, const void* B, int ldb, int b_kmajor, void* C, int ldc,
@@ -822,7 +824,7 @@ int vqa_gemm_fused_rows(const void* A, int lda, int a_kmajor, const void* B, int
     VQA_REQUIRE(C && ldc >= N, "vqa_gemm_fused: bad output");
     VQA_REQUIRE(act == 0 || act == 1, "vqa_gemm_fused: act must be 0 (none) or 1 (tanh)");
     VQA_REQUIRE(out_dtype == VQA_F32 || out_dtype == VQA_BF16, "vqa_gemm_fused: out_dtype");
-    Epi epi{C, ldc, out_dtype == VQA_BF16, 0, bias, row_scale, act, active_rows};
+    Epi epi{C, ldc, out_dtype == VQA_BF16, 0, bias, row_scale, act, active_rows, nullptr};
     if (dtype == VQA_BF16 && engine != 1) launch_bf16(A, lda, a_kmajor, B, ldb, b_kmajor, M, N, K, 1, engine, epi, stream);
     else if (dtype == VQA_BF16) launch_valu<bf16_t>(A, lda, a_kmajor, B, ldb, b_kmajor, M, N, K, 1, epi, stream);
     else launch_valu<float>(A, lda, a_kmajor, B, ldb, b_kmajor, M, N, K, 1, epi, stream);

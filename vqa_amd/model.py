@@ -117,7 +117,7 @@ class _VQAHeadModel(nn.Module):
                  attention_dim: int = FUSION_IN, fusion_in: int = FUSION_IN,
                  fusion_hidden: int = FUSION_HIDDEN, hops: int = 1, dropout: float = DROPOUT_F,
                  caption_vocab: int = 0, caption_dim: int = 384, seed: int = 0, gemm_engine: int = 0,
-                 seq2vec_arch: str = 'lstm', seq2vec_dropout: float = 0.3):
+                 seq2vec_arch: str = 'lstm', seq2vec_dropout: float = 0.3, train_encoder: bool = False):
         super().__init__()
         self.args = args
         self.vocab_questions = vocab_questions
@@ -144,8 +144,11 @@ class _VQAHeadModel(nn.Module):
             raise ValueError('question_out must be a multiple of 16 for the 2-lstm encoder (two halves of 8-element chunks)')
         self.seq2vec = _Seq2Vec(len(vocab_questions), emb_size, question_out, gen, seq2vec_arch)
         self.seq2vec_dropout = float(seq2vec_dropout)      # F.dropout(p=0.3) on each TwoLSTM vector, seq2vec.py:73-74
-        for p in self.seq2vec.parameters():          # frozen, as model.py:42-43
-            p.requires_grad = False
+        self.train_encoder = bool(train_encoder)
+        if self.train_encoder and emb_size > 1024:
+            raise ValueError('a trainable question encoder needs emb_size <= 1024')
+        for p in self.seq2vec.parameters():          # frozen as model.py:42-43 unless train_encoder
+            p.requires_grad = self.train_encoder
         self._build_visual(gen)
         self.linear_q = nn.Linear(self.Hq, self.F)
         self.linear_v = nn.Linear(self.Dv, self.F)
@@ -176,6 +179,7 @@ class _VQAHeadModel(nn.Module):
         self.grad_ready_hook = None   # callable(bucket_index) fired as gradient buckets complete
         self.kernel_events = None     # set to {} to collect per-kernel HIP event pairs
         self._pending = None          # last gradient bucket of the previous train_step still in flight
+        self._bptt = False            # the running forward keeps the encoder state for backward through time
 
     # ------------------------------------------------------------------ flat parameter storage
     def _trainable_order(self) -> List[Tuple[str, nn.Parameter]]:
@@ -185,7 +189,22 @@ class _VQAHeadModel(nn.Module):
                ('linear_classif1.weight', self.linear_classif1.weight), ('linear_classif1.bias', self.linear_classif1.bias),
                ('linear_v.weight', self.linear_v.weight), ('linear_v.bias', self.linear_v.bias),
                ('linear_q.weight', self.linear_q.weight), ('linear_q.bias', self.linear_q.bias)]
-        return out + self._visual_trainable_order()
+        return out + self._visual_trainable_order() + self._encoder_trainable_order()
+
+    def _enc_names(self):
+        return ['rnn'] if self.seq2vec.arch == 'lstm' else ['rnn_0', 'rnn_1']
+
+    def _encoder_trainable_order(self):
+        """Question-encoder parameters (when trainable) in the order backward through time completes
+        them: last layer first, the embedding table last."""
+        if not self.train_encoder:
+            return []
+        out = []
+        for nm, rnn in reversed(list(zip(self._enc_names(), self.seq2vec.layers))):
+            pre = f'seq2vec.{nm}.'
+            out += [(pre + 'bias_ih_l0', rnn.bias_ih_l0), (pre + 'bias_hh_l0', rnn.bias_hh_l0),
+                    (pre + 'weight_hh_l0', rnn.weight_hh_l0), (pre + 'weight_ih_l0', rnn.weight_ih_l0)]
+        return out + [('seq2vec.embedding.weight', self.seq2vec.embedding.weight)]
 
     def _materialize(self, device: torch.device):
         """Move trainable parameters into one flat fp32 buffer (parameters become
@@ -219,7 +238,8 @@ class _VQAHeadModel(nn.Module):
         self._shadow_version = -1
         # bucket boundaries (element ranges of the flat buffer) in completion order
         names = [n for n, _ in order]
-        cuts = sorted({names.index(n) for n in ['linear_v.weight'] + self._visual_bucket_starts()})
+        enc = [self._encoder_trainable_order()[0][0]] if self.train_encoder else []
+        cuts = sorted({names.index(n) for n in ['linear_v.weight'] + self._visual_bucket_starts() + enc})
         starts = [0] + [offsets[c][0] for c in cuts]
         ends = starts[1:] + [total]
         self.buckets = [(s, e) for s, e in zip(starts, ends) if e > s]
@@ -320,14 +340,14 @@ class _VQAHeadModel(nn.Module):
         return self._slab
 
     # ------------------------------------------------------------------ kernel helpers
-    def _gemm_slabs(self, A, lda, akm, Bm, ldb, bkm, M, N, K, active_rows=None):
+    def _gemm_slabs(self, A, lda, akm, Bm, ldb, bkm, M, N, K, active_rows=None, active_k=None):
         """fp32 partial sums of A B^T into the slab workspace -> (slab tensor, nslab, stride).
         active_rows: device address of an int32 row count past which output tiles are skipped."""
         sk = call('vqa_gemm_splitk_hint', M, N, K, akm, bkm)
         stride = M * N
         slab = self._slabs(sk * stride, A.device)
         call('vqa_gemm_slabs_rows', ptr(A), lda, akm, ptr(Bm), ldb, bkm, ptr(slab), stride, N, M, N, K, sk,
-             self.dt, self.gemm_engine, active_rows)
+             self.dt, self.gemm_engine, active_rows, active_k)
         return slab, sk, stride
 
     def _linear(self, x, ldx, wname, bname, M, N, K, *, act=0, out_pre=None, ld_pre=0, out_post=None, ld_post=0,
@@ -338,9 +358,9 @@ class _VQAHeadModel(nn.Module):
              ptr(addend), ld_add, act, ptr(out_pre), ld_pre, ptr(out_post), ld_post,
              self.dt if post_dtype is None else post_dtype, seed, p)
 
-    def _wgrad(self, dy, ld_dy, x, ldx, wname, M, N, K):
+    def _wgrad(self, dy, ld_dy, x, ldx, wname, M, N, K, active_k=None):
         """grad(W)[M,N] = dy^T x with dy stored [K][M], x stored [K][N]."""
-        slab, sk, stride = self._gemm_slabs(dy, ld_dy, 0, x, ldx, 0, M, N, K)
+        slab, sk, stride = self._gemm_slabs(dy, ld_dy, 0, x, ldx, 0, M, N, K, active_k=active_k)
         call('vqa_epilogue', ptr(slab), sk, stride, M, N, None, None, None, 0, 0, ptr(self._g(wname)), N,
              None, 0, _lib.F32, 0, 0.0)
 
@@ -381,8 +401,10 @@ class _VQAHeadModel(nn.Module):
         self._materialize(tokens.device)
         params = [p for _, p in self._trainable_order()]
         if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+            self._bptt = True
             return _VQAFunction.apply(self, feats, tokens, captions, *params)
         # the returned tensor is a copy: the workspace is reused by the next call
+        self._bptt = False
         return self._forward_impl(feats, tokens, captions).clone()
 
     def _drop_seeds(self):
@@ -409,14 +431,16 @@ class _VQAHeadModel(nn.Module):
         # m_t[t] and their input projections are rows offs[t].. of xg; padding steps cost nothing
         call('vqa_sequence_pack', ptr(tokens), B, L, ptr(ws['len']), ptr(ws['perm']), ptr(ws['m_t']), ptr(ws['offs']))
         call('vqa_embedding_gather_packed', ptr(tokens), ptr(self._emb_t), ptr(ws['x_emb']), B, L, Ep, Ep, Ep,
-             self._emb_t.shape[0], ptr(ws['perm']), ptr(ws['offs']), 1 if two else 0, dt)
+             self._emb_t.shape[0], ptr(ws['perm']), ptr(ws['offs']), 1 if two else 0, ptr(ws.get('ptok')), dt)
         total_rows = ws['offs'].data_ptr() + 4 * L
         x, kin = ws['x_emb'], Ep
         esz = ws['qT'].element_size()
         for li, (wih, whh, bias) in enumerate(self._enc_layers):
             Hh = whh.shape[1]
             last_layer = li + 1 == len(self._enc_layers)
-            hs = None if last_layer else ws['hs']
+            save = self.train_encoder and self._bptt
+            hs = ws[f'hs{li}'] if save else (None if last_layer else ws['hs'])
+            gates, cs = (ws[f'gates{li}'], ws[f'cs{li}']) if save else (None, None)
             call('vqa_gemm_fused_rows', ptr(x), kin, 1, ptr(wih), kin, 1, ptr(ws['xg']), 4 * Hh,
                  L * B, 4 * Hh, kin, ptr(bias), None, 0, dt, dt, self.gemm_engine, total_rows)
             q32 = ws['q32'].data_ptr() + 4 * li * Hh            # this layer's columns of q
@@ -429,7 +453,7 @@ class _VQAHeadModel(nn.Module):
                                                         active_rows=ws['m_t'].data_ptr() + 4 * t)
                 call('vqa_lstm_cell_packed', ptr(slab), sk, stride, ptr(ws['xg']), 4 * Hh, ptr(ws['c']), ptr(ws['h']), Hh,
                      ptr(ws['len']), q32, qT, Hq, B, Hh, t, L, ptr(ws['perm']), ptr(ws['m_t']),
-                     ptr(ws['offs']), ptr(hs), Hh, dt)
+                     ptr(ws['offs']), ptr(hs), Hh, ptr(gates), ptr(cs), dt)
             x, kin = hs, Hh
         if two and self.training and self.seq2vec_dropout > 0.0 and seeds is not None:
             Hh = Hq // 2
@@ -459,6 +483,15 @@ class _VQAHeadModel(nn.Module):
                    'c': z((B, Hh), f32), 'h': z((B, Hh), tdt), 'q32': z((B, H), f32), 'qT': z((B, H), tdt)})
         if len(self.seq2vec.layers) > 1:
             ws['hs'] = z((L * B, Hh), tdt)
+        if self.train_encoder:                        # state kept for backward through time
+            ws['ptok'] = z((L * B,), torch.int32)
+            for li, rnn in enumerate(self.seq2vec.layers):
+                h = rnn.hidden_size
+                ws[f'gates{li}'] = z((L * B, 4 * h), tdt)
+                ws[f'cs{li}'] = z((L * B, h), f32)
+                ws[f'hs{li}'] = z((L * B, h), tdt)
+            ws.update({'dG': z((L * B, 4 * Hh), tdt), 'dgs': z((B, 4 * Hh), tdt), 'hprev': z((L * B, Hh), tdt),
+                       'dc': z((B, Hh), f32), 'dq32': z((B, H), f32), 'dh_ext': z((L * B, Hh), f32)})
 
     def _forward_impl(self, feats, tokens, captions):
         B, L = tokens.shape
@@ -473,6 +506,9 @@ class _VQAHeadModel(nn.Module):
 
         # parameter-independent prologue first: a gradient bucket still being all-reduced from the
         # previous train_step (and its Adam update) is only needed from here on
+        if self.train_encoder:
+            self._finish_pending()               # the deferred bucket holds the encoder's own weights
+            self._frozen_key = None              # they change every step: refresh the operand copies
         self.encode_question(tokens, ws, seeds[4:6])
         self._visual_prologue(ws, feats, B)
         self._finish_pending()
@@ -528,7 +564,65 @@ class _VQAHeadModel(nn.Module):
         slab, sk, st = self._gemm_slabs(ws['dzv'], F, 1, self._w('linear_v.weight'), Dv, 0, B, Dv, F)
         call('vqa_epilogue', ptr(slab), sk, st, B, Dv, None, None, None, 0, 0, None, 0, ptr(ws['d_pooled']), Dv,
              _lib.F32, seeds[0], p)
+        if self.train_encoder:                  # d loss / d q through linear_q and its dropout (model.py:67-68)
+            slab, sk, st = self._gemm_slabs(ws['dzq'], F, 1, self._w('linear_q.weight'), H, 0, B, H, F)
+            call('vqa_epilogue', ptr(slab), sk, st, B, H, None, None, None, 0, 0, None, 0, ptr(ws['dq32']), H,
+                 _lib.F32, seeds[1], p)
         self._visual_backward(ws, feats, B)
+        if self.train_encoder:
+            self._encoder_backward(ws, B, L, seeds)
+
+    def _add_dq(self, ws, B, slab, sk, st):
+        """dq += sum of the slabs (a front-end's contribution to d loss / d q)."""
+        H = self.Hq
+        call('vqa_epilogue', ptr(slab), sk, st, B, H, None, None, ptr(ws['dq32']), H, 0, ptr(ws['dq32']), H,
+             None, 0, _lib.F32, 0, 0.0)
+
+    def _encoder_backward(self, ws, B, L, seeds):
+        """Backward through time of the packed LSTM layer(s) from ws['dq32'], weight / bias / embedding
+        gradients into the flat gradient buffer (autograd of seq2vec.py:42-43, 63-75 restated)."""
+        Hq, dt, Ep = self.Hq, self.dt, _pad8(self.E)
+        two = self.seq2vec.arch == '2-lstm'
+        total = ws['offs'].data_ptr() + 4 * L
+        if two and self.training and self.seq2vec_dropout > 0.0:
+            Hh = Hq // 2
+            for li in range(2):
+                a = ws['dq32'].data_ptr() + 4 * li * Hh
+                call('vqa_dropout', a, Hq, a, Hq, B, Hh, seeds[4 + li], self.seq2vec_dropout, _lib.F32)
+        names = self._enc_names()
+        dh_ext = None
+        for li in reversed(range(len(self._enc_layers))):
+            wih, whh, _ = self._enc_layers[li]
+            Hh, kin = whh.shape[1], wih.shape[1]
+            pre = f'seq2vec.{names[li]}.'
+            rnn = self.seq2vec.layers[li]
+            x_in = ws['x_emb'] if li == 0 else ws[f'hs{li - 1}']
+            dq_l = ws['dq32'].data_ptr() + 4 * li * Hh
+            for t in reversed(range(L)):
+                if t == L - 1:
+                    slab, sk, st = None, 0, 0
+                else:                             # dh_t from the step after: dG_{t+1} W_hh
+                    slab, sk, st = self._gemm_slabs(ws['dgs'], 4 * Hh, 1, whh, Hh, 0, B, Hh, 4 * Hh,
+                                                    active_rows=ws['m_t'].data_ptr() + 4 * (t + 1))
+                call('vqa_lstm_cell_bwd_packed', ptr(slab), sk, st, dq_l, Hq, ptr(dh_ext), ptr(ws[f'gates{li}']),
+                     ptr(ws[f'cs{li}']), ptr(ws[f'hs{li}']), ptr(ws['dc']), ptr(ws['dG']), ptr(ws['dgs']), ptr(ws['hprev']),
+                     ptr(ws['len']), ptr(ws['perm']), ptr(ws['m_t']), ptr(ws['offs']), B, Hh, t, L, dt)
+            g = self._g
+            call('vqa_colsum_rows', ptr(ws['dG']), 4 * Hh, ptr(g(pre + 'bias_ih_l0')), total, 4 * Hh, dt)
+            call('vqa_colsum_rows', ptr(ws['dG']), 4 * Hh, ptr(g(pre + 'bias_hh_l0')), total, 4 * Hh, dt)
+            self._wgrad(ws['dG'], 4 * Hh, ws['hprev'], Hh, pre + 'weight_hh_l0', 4 * Hh, Hh, L * B, active_k=total)
+            self._wgrad(ws['dG'], 4 * Hh, x_in, kin, pre + 'weight_ih_l0', 4 * Hh, rnn.input_size, L * B, active_k=total)
+            # gradient at the layer's input sequence: dX = dG W_ih
+            slab, sk, st = self._gemm_slabs(ws['dG'], 4 * Hh, 1, wih, kin, 0, L * B, kin, 4 * Hh, active_rows=total)
+            if li > 0:
+                call('vqa_epilogue', ptr(slab), sk, st, L * B, kin, None, None, None, 0, 0, ptr(ws['dh_ext']), kin,
+                     None, 0, _lib.F32, 0, 0.0)
+                dh_ext = ws['dh_ext']
+            else:
+                emb = self.seq2vec.embedding.weight
+                call('vqa_embedding_grad', ptr(slab), sk, st, kin, ptr(ws['ptok']), total,
+                     ptr(ws['x_emb']) if two else None, Ep, ptr(g('seq2vec.embedding.weight')), emb.shape[0], self.E, dt)
+        self._bucket_done('seq2vec.embedding.weight')
 
     # ------------------------------------------------------------------ loss / prediction / step
     def loss_and_grad_logits(self, answers: torch.Tensor) -> torch.Tensor:
@@ -598,6 +692,7 @@ class _VQAHeadModel(nn.Module):
         self._materialize(tokens.device)
         betas, eps = (0.9, 0.999), 1e-8
         with torch.no_grad():
+            self._bptt = True
             self._forward_impl(feats, tokens, captions)
             loss = self.loss_and_grad_logits(answers)
             if reducer is not None:
@@ -775,6 +870,11 @@ class VQAAttnModel(_VQAHeadModel):
                 du_carry = ws['du32']
                 self._wgrad(ws['duT'], H, ws[f'pooled{k - 1}'], Dv, ppre + 'linear_u.weight', H, Dv, B)
                 call('vqa_colsum', ptr(ws['du32']), H, ptr(g(ppre + 'linear_u.bias')), B, H, _lib.F32)
+            elif self.train_encoder:              # d q = dqa W_qa (+ the carry of the later hops: u^1 = q + ...)
+                slab, sk, st = self._gemm_slabs(ws['dqaT'], A, 1, self._w(pre + 'linear_qa.weight'), H, 0, B, H, A)
+                self._add_dq(ws, B, slab, sk, st)
+                if du_carry is not None:
+                    self._add_dq(ws, B, du_carry, 1, 0)
             self._bucket_done(pre + 'linear_va.bias')
             self._wgrad(ws['dP'], A, feats, Dv, pre + 'linear_va.weight', A, Dv, B * R)
             self._bucket_done(pre + 'linear_va.weight')
@@ -866,6 +966,9 @@ class VQAGAPModel(_VQAHeadModel):
         call('vqa_colsum', ptr(ws['dzg']), Dv, ptr(self._g('gap1.0.bias')), B, Dv, self.dt)
         self._wgrad(ws['dzg'], Dv, ws['qT'], H, 'gap1.0.weight', Dv, H, B)
         self._bucket_done('gap1.0.weight')
+        if self.train_encoder:                    # the gates read the question vector (model.py:166-169)
+            slab, sk, st = self._gemm_slabs(ws['dzg'], Dv, 1, self._w('gap1.0.weight'), H, 0, B, H, Dv)
+            self._add_dq(ws, B, slab, sk, st)
 
     def _w(self, name):
         if name == 'gap1.0.weight':           # all gate weights as one (Dv, Hq) matrix

@@ -59,6 +59,7 @@ def evaluate(model, dataset, meter):
     running = torch.zeros(1, device=meter.counters.device)
     with torch.no_grad():
         for question, answer, image, types in dataset:
+            model._bptt = False
             model._forward_impl(*model._prepare_inputs(image, question, None))
             running += model.loss_and_grad_logits(answer) * question.shape[0]
             meter.update(model, answer, types)
