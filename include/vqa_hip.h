@@ -148,6 +148,16 @@ int vqa_gate_fwd(const float* slabs, int nslab, size_t slab_stride, const float*
 int vqa_gate_bwd(const float* d_out, int ld_d, const float* mean, int ld_mean, const float* gate, int ld_gate,
                  void* dz, int ld_dz, int B, int N, int dtype, hipStream_t stream);
 
+/* Weighted stack of K gated vectors sig (B, K, D) fp32, then max and mean over the stack, concatenated and
+ * dropped: out[b, 0:D] = max_k w[k] sig[b,k,:], out[b, D:2D] = mean_k w[k] sig[b,k,:]; argmax[b, d] = the k of
+ * the maximum (first on ties); weight k is w[k * ld_w].        model.py:1238-1241 (stack, mean, max, cat) */
+int vqa_stack_maxavg_fwd(const float* sig, const float* w, int ld_w, void* out, int ld_out, unsigned char* argmax, int B, int D,
+                         int K, unsigned seed, float p, int dtype, hipStream_t stream);
+/* backward of the above: dz (B, K, D) = gradient at the pre-activation of each gate's sigmoid,
+ * dw_part (B, K) = per-sample partial gradients of the stack weights (summed over b by vqa_colsum) */
+int vqa_stack_maxavg_bwd(const float* d_out, int ld_d, const float* sig, const float* w, int ld_w, const unsigned char* argmax,
+                         void* dz, float* dw_part, int B, int D, int K, int dtype, hipStream_t stream);
+
 /* out[b, ch * R + r] = dropout(y[b * R + r, ch]): the NCHW .view(-1, VISUAL_OUT) of the 1x1-convolved
  * map followed by dropoutV                                              model.py:54, 61-62 */
 int vqa_flatten_cm(const void* y, int ld_y, void* out, int ld_out, int B, int R, int c, unsigned seed, float p,
@@ -183,7 +193,7 @@ int vqa_gemm_fused(const void* A, int lda, int a_kmajor, const void* B, int ldb,
 
 /* ---- split-K reduce + epilogues of the head ------------------------------------ */
 
-/* v = act(row_scale[m] * sum_s slabs[s][m][n] + bias[n] + addend[m][n]);
+/* v = act(row_scale[m] * sum_s slabs[s][m][n] + bias[n] + addend[m][n]), act 0 none, 1 tanh, 2 sigmoid;
  * out_pre (fp32) = v; out_post (post_dtype) = dropout(v).  Either output may be NULL. */
 int vqa_epilogue(const float* slabs, int nslab, size_t slab_stride, int M, int N, const float* bias,
                  const float* row_scale, const float* addend, int ld_add, int act, float* out_pre, int ld_pre,

@@ -187,6 +187,21 @@ def gated_gap(maps: Sequence[torch.Tensor], q: torch.Tensor, p: Dict[str, torch.
     return torch.cat(parts, dim=1)
 
 
+STACK_WIRING = (1, 3, 4, 2)     # stack slot i holds dim_chg_gap{k}(mean of stage k), k = STACK_WIRING[i] (model.py:1234-1237)
+
+
+def stack_max_avg(maps: Sequence[torch.Tensor], p: Dict[str, torch.Tensor]) -> torch.Tensor:
+    """Max / mean over the weighted stack of the four gated stage vectors (model.py:1225-1241):
+    s_k = sigmoid(dim_chg_gap_k(mean_k)); stacked = [w1 s_1, w2 s_3, w3 s_4, w4 s_2]; cat(max, mean)."""
+    st = []
+    for i, k in enumerate(STACK_WIRING):
+        avg = maps[k - 1].mean(dim=(2, 3))
+        s = torch.sigmoid(avg @ p[f'dim_chg_gap{k}.0.weight'].t() + p[f'dim_chg_gap{k}.0.bias'])
+        st.append(p[f'w{i + 1}'] * s)
+    stacked = torch.stack(st, 2)
+    return torch.cat((stacked.max(dim=2).values, stacked.mean(dim=2)), dim=1)
+
+
 def conv_flatten(fmap: torch.Tensor, p: Dict[str, torch.Tensor]) -> torch.Tensor:
     """VQAModel's visual vector: Conv2d(Dv, Dv / (H W), 1) over the last ResNet map (model.py:53-54)
     then .view(-1, VISUAL_OUT) of the NCHW result (model.py:61): channel-major flatten."""
@@ -220,6 +235,9 @@ def forward(p: Dict[str, torch.Tensor], feats, tokens: torch.Tensor,
         hops = 0
     elif mode == 'conv':
         pooled = conv_flatten(feats, p)
+        hops = 0
+    elif mode == 'stack':
+        pooled = stack_max_avg(feats, p)
         hops = 0
     else:
         v_hat = l2_normalise(feats)
@@ -342,6 +360,12 @@ def init_params(vq: int, C: int, E: int, Hq: int, Dv: int, A: int, F: int, Hf: i
         for k, ck in enumerate(gap_channels, 1):
             linear(f'gap{k}.0', ck, Hq, p)
         Dv = sum(gap_channels)
+    elif mode == 'stack':           # model.py:1187-1207; Dv here = the common gate width (2048 upstream)
+        for k, ck in enumerate(gap_channels, 1):
+            linear(f'dim_chg_gap{k}.0', Dv, ck, p)
+        for i in range(4):
+            p[f'w{i + 1}'] = torch.tensor(0.25, dtype=dtype) + uni((), 0.1)      # 0.25 upstream (model.py:1204-1207), spread for the test
+        Dv = 2 * Dv
     elif mode == 'conv':            # model.py:54: Conv2d(Dv, conv_out, 1); default init bound 1/sqrt(fan_in)
         b = 1.0 / math.sqrt(Dv)
         p['visual.1.weight'] = uni((conv_out, Dv, 1, 1), b)

@@ -101,10 +101,24 @@ def _check(m, po, vis_ref, vis_gpu, b, mode, dtype, train):
     loss.backward()
     assert abs(float(loss.detach()) - float(loss_ref)) <= tol * max(1.0, abs(float(loss_ref)))
     named = dict(m.named_parameters())
+    scalars = [k for k in grads_ref if grads_ref[k].dim() == 0]
     for k, gref in grads_ref.items():
         assert named[k].grad is not None, k
+        if k in scalars:
+            continue
         noise = rel_err(gref, grads64[k])
+        if mode == 'stack' and dtype == torch.bfloat16 and k.startswith('dim_chg_gap'):
+            # the max over the stack is discontinuous: bf16 rounding flips the winner of a few near-ties, which moves
+            # single rows of these gradients; judged in the L2 norm instead of element-wise
+            diff = (named[k].grad.double().cpu() - grads64[k]).norm() / grads64[k].norm()
+            assert float(diff) <= 0.15, (k, float(diff))       # the fp32 run of this test is the strict one
+            continue
         assert rel_err(named[k].grad, grads64[k]) <= max(2 * tol, 4 * noise), (k, rel_err(named[k].grad, grads64[k]), noise)
+    if scalars:
+        # scalar weights: each gradient is a sum over the whole batch that largely cancels; judged as one vector
+        got = torch.stack([named[k].grad.cpu() for k in scalars])
+        ref = torch.stack([grads64[k] for k in scalars])
+        assert rel_err(got, ref) <= (1e-4 if dtype == torch.float32 else 5e-2), (got, ref)
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
@@ -200,3 +214,23 @@ def test_train_driver_gap_model_and_resume(tmp_path):
     sa, sb = m.state_dict(), m2.state_dict()
     for k in sa:
         assert torch.equal(sa[k], sb[k]), k
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('kw,channels,grids,B', [(TINY, (8, 16, 24, 32), (8, 4, 4, 2), 4),
+                                                 (MID, (32, 64, 128, 256), (16, 8, 4, 2), 19)])
+def test_stack_max_avg_model_forward_backward(dtype, kw, channels, grids, B):
+    """Max / mean over the weighted stack of gated stage vectors (model.py:1234-1241), incl. the
+    cross-wiring of stages to stack slots and the gradients of the scalar stack weights."""
+    from vqa_amd.model import VQAGAPStackModel
+    D = kw['Dv']
+    p = vqa_ref.init_params(seed=3, mode='stack', gap_channels=channels, **kw)
+    m = VQAGAPStackModel(['w'] * kw['vq'], ['a'] * kw['C'], None, dtype=dtype, emb_size=kw['E'], question_out=kw['Hq'],
+                         fusion_in=kw['F'], fusion_hidden=kw['Hf'], gap_channels=channels, stack_dim=D, seed=1234)
+    m.load_state_dict(p)
+    m = m.to('cuda')
+    maps = [x.to(dtype) for x in vqa_ref.synthetic_maps(B, channels, grids, seed=9)]
+    b = vqa_ref.synthetic_batch(B, 4, 8, 14, kw['vq'], kw['C'], seed=5)
+    po = p if dtype == torch.float32 else {k: v.to(torch.bfloat16).float() for k, v in p.items()}
+    _check(m, po, [x.float() for x in maps], [x.cuda() for x in maps], b, 'stack', dtype, train=False)
+    _check(m, po, [x.float() for x in maps], [x.cuda() for x in maps], b, 'stack', dtype, train=True)

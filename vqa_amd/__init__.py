@@ -5,7 +5,7 @@ PyTorch-ROCm through ctypes.  There is no CPU fallback.
 """
 from .vocab_encoder import VocabEncoder  # noqa: F401
 
-_MODELS = ('VQAAttnModel', 'VQAGAPModel', 'VQAModel')
+_MODELS = ('VQAAttnModel', 'VQAGAPModel', 'VQAGAPStackModel', 'VQAModel')
 __all__ = ['VocabEncoder', *_MODELS]
 
 

@@ -36,6 +36,8 @@ _SIGNATURES = {
     'vqa_grid_mean': [_p, _i, _i, _i, _i, _p, _i, _i, _p, _i, _i, _p],
     'vqa_gate_fwd': [_p, _i, _z, _p, _p, _i, _p, _i, _p, _i, _i, _i, _u, _f, _i, _p],
     'vqa_gate_bwd': [_p, _i, _p, _i, _p, _i, _p, _i, _i, _i, _i, _p],
+    'vqa_stack_maxavg_fwd': [_p, _p, _i, _p, _i, _p, _i, _i, _i, _u, _f, _i, _p],
+    'vqa_stack_maxavg_bwd': [_p, _i, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _p],
     'vqa_flatten_cm': [_p, _i, _p, _i, _i, _i, _i, _u, _f, _i, _p],
     'vqa_unflatten_cm': [_p, _i, _p, _i, _i, _i, _i, _i, _p],
     'vqa_attn_lds_bytes': [_i, _i, _i],

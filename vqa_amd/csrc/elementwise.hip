@@ -324,6 +324,7 @@ __global__ void k_epilogue(const float* __restrict__ slabs, int nslab, size_t sl
         if (bias) v += bias[n];
         if (addend) v += addend[(size_t)m * ld_add + n];
         if (act == 1) v = accurate ? tanhf(v) : fast_tanh(v);
+        else if (act == 2) v = accurate ? 1.0f / (1.0f + expf(-v)) : fast_sigmoid(v);
         if (out_pre) out_pre[(size_t)m * ld_pre + n] = v;
         if (out_post) out_post[(size_t)m * ld_post + n] = from_f32<TP>(v * drop_mult(seed, (unsigned)i, thr, dscale));
     }
@@ -793,7 +794,7 @@ int vqa_epilogue(const float* slabs, int nslab, size_t slab_stride, int M, int N
                  void* out_post, int ld_post, int post_dtype, unsigned drop_seed, float drop_p, hipStream_t stream) {
     VQA_REQUIRE(slabs && nslab >= 1 && M >= 0 && N > 0, "vqa_epilogue: bad arguments");
     VQA_REQUIRE(out_pre || out_post, "vqa_epilogue: no output");
-    VQA_REQUIRE(act == 0 || act == 1, "vqa_epilogue: act must be 0 (none) or 1 (tanh)");
+    VQA_REQUIRE(act >= 0 && act <= 2, "vqa_epilogue: act must be 0 (none), 1 (tanh) or 2 (sigmoid)");
     VQA_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "vqa_epilogue: drop_p must be in [0, 1)");
     if (M == 0) return 0;
     const unsigned thr = drop_threshold(drop_p);

@@ -150,6 +150,58 @@ __global__ void k_gate_bwd(const float* __restrict__ d_out, int ld_d, const floa
 }
 
 // ---------------------------------------------------------------------------
+// weighted stack of K gated vectors, then max and mean over the stack (model.py:1238-1241):
+//   st_k = w[k] * sig[b, k, d];  out[b, d] = max_k st_k;  out[b, D + d] = mean_k st_k   (both times dropout)
+//   arg[b, d] = the k of the maximum (first one on ties, as torch.max)
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void k_stack_maxavg_fwd(const float* __restrict__ sig, const float* __restrict__ w, int ld_w, T* __restrict__ out,
+                                   int ld_out, unsigned char* __restrict__ arg, int B, int D, int K,
+                                   unsigned seed, unsigned thr, float dscale) {
+    const long total = (long)B * D;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long b = i / D;
+        const int d = (int)(i % D);
+        float mx = -INFINITY, sum = 0.f;
+        int am = 0;
+        for (int k = 0; k < K; ++k) {
+            const float v = w[(size_t)k * ld_w] * sig[((size_t)b * K + k) * D + d];
+            sum += v;
+            if (v > mx) { mx = v; am = k; }
+        }
+        arg[i] = (unsigned char)am;
+        const unsigned i_max = (unsigned)(b * 2 * D + d), i_avg = i_max + (unsigned)D;   // index in the (B, 2D) output
+        out[(size_t)b * ld_out + d] = from_f32<T>(mx * drop_mult(seed, i_max, thr, dscale));
+        out[(size_t)b * ld_out + D + d] = from_f32<T>(sum * (1.0f / (float)K) * drop_mult(seed, i_avg, thr, dscale));
+    }
+}
+
+// backward: d_st_k = d_out[b, d] [k == arg] + d_out[b, D + d] / K;
+//   dz[b, k, d] = d_st_k * w[k] * s (1 - s)   (pre-activation of the gate's sigmoid)
+//   dw_part[b, k] = sum_d d_st_k * s          (one block per sample, fixed-order reduction)
+template <typename T>
+__global__ void __launch_bounds__(256) k_stack_maxavg_bwd(const float* __restrict__ d_out, int ld_d,
+                                  const float* __restrict__ sig, const float* __restrict__ w, int ld_w,
+                                  const unsigned char* __restrict__ arg, T* __restrict__ dz,
+                                  float* __restrict__ dw_part, int D, int K) {
+    __shared__ float red[8];
+    const int b = blockIdx.x;
+    for (int k = 0; k < K; ++k) {
+        const float wk = w[(size_t)k * ld_w];
+        float part = 0.f;
+        for (int d = threadIdx.x; d < D; d += blockDim.x) {
+            const float s = sig[((size_t)b * K + k) * D + d];
+            const float dst = (arg[(size_t)b * D + d] == k ? d_out[(size_t)b * ld_d + d] : 0.f) +
+                              d_out[(size_t)b * ld_d + D + d] * (1.0f / (float)K);
+            dz[((size_t)b * K + k) * D + d] = from_f32<T>(dst * wk * s * (1.0f - s));
+            part += dst * s;
+        }
+        part = block_sum(part, red);
+        if (threadIdx.x == 0) dw_part[(size_t)b * K + k] = part;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // channel-major flatten of a (B*R, c) product:  out[b, ch * R + r] = y[b * R + r, ch] * dropout(b * c * R + ch * R + r)
 // (the .view(-1, VISUAL_OUT) of an NCHW tensor, model.py:61) and its transpose for the backward pass.
 // ---------------------------------------------------------------------------
@@ -249,6 +301,27 @@ int vqa_gate_bwd(const float* d_out, int ld_d, const float* mean, int ld_mean, c
     DISPATCH_T(dtype, (k_gate_bwd<T><<<grid_for((long)B * N, 256), 256, 0, stream>>>(
         d_out, ld_d, mean, ld_mean, gate, ld_gate, (T*)dz, ld_dz, B, N)));
     return vqa_check_launch("vqa_gate_bwd");
+}
+
+int vqa_stack_maxavg_fwd(const float* sig, const float* w, int ld_w, void* out, int ld_out, unsigned char* argmax, int B, int D,
+                         int K, unsigned seed, float p, int dtype, hipStream_t stream) {
+    VQA_REQUIRE(sig && w && ld_w >= 1 && out && argmax && B >= 0 && D > 0 && K >= 1 && K <= 255 && ld_out >= 2 * D && p >= 0.f && p < 1.f,
+                "vqa_stack_maxavg_fwd: bad arguments");
+    if (B == 0) return 0;
+    const unsigned thr = drop_threshold(p);
+    const float ds = 1.0f / (1.0f - p);
+    DISPATCH_T(dtype, (k_stack_maxavg_fwd<T><<<grid_for((long)B * D, 256), 256, 0, stream>>>(
+        sig, w, ld_w, (T*)out, ld_out, argmax, B, D, K, seed, thr, ds)));
+    return vqa_check_launch("vqa_stack_maxavg_fwd");
+}
+
+int vqa_stack_maxavg_bwd(const float* d_out, int ld_d, const float* sig, const float* w, int ld_w, const unsigned char* argmax,
+                         void* dz, float* dw_part, int B, int D, int K, int dtype, hipStream_t stream) {
+    VQA_REQUIRE(d_out && sig && w && ld_w >= 1 && argmax && dz && dw_part && B >= 0 && D > 0 && K >= 1 && K <= 255 && ld_d >= 2 * D,
+                "vqa_stack_maxavg_bwd: bad arguments");
+    if (B == 0) return 0;
+    DISPATCH_T(dtype, (k_stack_maxavg_bwd<T><<<B, 256, 0, stream>>>(d_out, ld_d, sig, w, ld_w, argmax, (T*)dz, dw_part, D, K)));
+    return vqa_check_launch("vqa_stack_maxavg_bwd");
 }
 
 int vqa_flatten_cm(const void* y, int ld_y, void* out, int ld_out, int B, int R, int c, unsigned seed, float p,

@@ -1052,3 +1052,92 @@ class VQAModel(_VQAHeadModel):
         call('vqa_colsum', ptr(ws['dy']), cp, ptr(self._g('visual.1.bias')), B * R, c, dt)
         self._wgrad(ws['dy'], cp, feats, Cin, 'visual.1.weight', c, Cin, B * R)
         self._bucket_done('visual.1.weight')
+
+
+class VQAGAPStackModel(_VQAHeadModel):
+    """Stage-mean pooling with the max / mean stack of the reference's BERT-side models
+    (model.py:1187-1207, 1225-1241) in front of the fusion head: each stage mean goes through
+    ``dim_chg_gapK = Sigmoid(Linear(C_k, D))``, the four D-wide vectors are weighted by the scalars
+    ``w1..w4``, stacked (with the reference's cross-wiring: slots hold stages 1, 3, 4, 2), and the
+    element-wise max and mean over the stack are concatenated into the 2 D-wide visual vector.
+    (Upstream that vector is a VisualBERT visual embedding; BERT is outside this package, so here it
+    enters ``linear_v`` of the head.)  ``input_v`` as for VQAGAPModel."""
+
+    WIRING = (1, 3, 4, 2)
+
+    def __init__(self, vocab_questions, vocab_answers, args=None, input_size: int = 512, *,
+                 gap_channels: Sequence[int] = (256, 512, 1024, 2048), stack_dim: int = 2048, **kw):
+        self.gap_channels = tuple(int(c) for c in gap_channels)
+        self.D = int(stack_dim)
+        if len(self.gap_channels) != 4 or any(c % 8 for c in self.gap_channels) or self.D % 8:
+            raise ValueError('four stage channel counts and stack_dim, all multiples of 8')
+        kw['visual_out'] = 2 * self.D
+        super().__init__(vocab_questions, vocab_answers, args, input_size, **kw)
+
+    def _build_visual(self, gen):
+        for k, c in enumerate(self.gap_channels, 1):        # names as model.py:1187-1202
+            setattr(self, f'dim_chg_gap{k}', nn.Sequential(nn.Linear(c, self.D), nn.Sigmoid()))
+        for i in range(1, 5):                               # model.py:1204-1207
+            setattr(self, f'w{i}', nn.Parameter(torch.tensor(0.25)))
+
+    def _visual_trainable_order(self):
+        out = [(f'w{i}', getattr(self, f'w{i}')) for i in range(1, 5)]     # adjacent: 8 floats apart in the flat buffer
+        for k in range(1, 5):
+            lin = getattr(self, f'dim_chg_gap{k}')[0]
+            out += [(f'dim_chg_gap{k}.0.bias', lin.bias), (f'dim_chg_gap{k}.0.weight', lin.weight)]
+        return out
+
+    def _visual_bucket_starts(self):
+        return ['w1']
+
+    _prepare_visual = VQAGAPModel._prepare_visual
+    _geometry = VQAGAPModel._geometry
+
+    def _visual_workspace(self, ws, z, B, geom):
+        f32, tdt = torch.float32, self.compute_dtype
+        Ct, D = sum(self.gap_channels), self.D
+        ws.update({'gmean': z((B, Ct), f32), 'gmeanT': z((B, Ct), tdt), 'sig': z((B, 4, D), f32),
+                   'arg': z((B, D), torch.uint8), 'dzs': z((B, 4, D), tdt), 'dw_part': z((B, 4), f32)})
+        nsp = [call('vqa_grid_mean_splits', layout, B, c, hw) for (hw, layout), c in zip(geom, self.gap_channels)]
+        ws['gm_splits'] = nsp
+        need = max([n * B * c for n, c in zip(nsp, self.gap_channels) if n > 1], default=0)
+        ws['gm_part'] = z((need,), f32) if need else None
+
+    def _visual_prologue(self, ws, maps, B):
+        Ct = sum(self.gap_channels)
+        col = 0
+        for (m, layout), c, nsp in zip(maps, self.gap_channels, ws['gm_splits']):
+            call('vqa_grid_mean', ptr(m), layout, B, c, m.shape[2] * m.shape[3], ptr(ws['gmean']), Ct, col,
+                 ptr(ws['gm_part']), nsp, self.dt)
+            col += c
+        call('vqa_cast_pad', ptr(ws['gmean']), Ct, ptr(ws['gmeanT']), Ct, B, Ct, self.dt)
+
+    def _cols(self):
+        out, col = {}, 0
+        for k, c in enumerate(self.gap_channels, 1):
+            out[k] = (col, c)
+            col += c
+        return out
+
+    def _visual_forward(self, ws, maps, B, seed, p):
+        Ct, D = sum(self.gap_channels), self.D
+        cols = self._cols()
+        for i, k in enumerate(self.WIRING):
+            col, c = cols[k]
+            slab, sk, st = self._gemm_slabs(ws['gmeanT'][:, col:], Ct, 1, self._w(f'dim_chg_gap{k}.0.weight'), c, 1, B, D, c)
+            call('vqa_epilogue', ptr(slab), sk, st, B, D, ptr(self._f32(f'dim_chg_gap{k}.0.bias')), None, None, 0, 2,
+                 ptr(ws['sig'][:, i]), 4 * D, None, 0, _lib.F32, 0, 0.0)
+        call('vqa_stack_maxavg_fwd', ptr(ws['sig']), ptr(self._f32('w1')), 8, ptr(ws['pooled_d']), 2 * D, ptr(ws['arg']),
+             B, D, 4, seed, p, self.dt)
+
+    def _visual_backward(self, ws, maps, B):
+        Ct, D = sum(self.gap_channels), self.D
+        cols = self._cols()
+        call('vqa_stack_maxavg_bwd', ptr(ws['d_pooled']), 2 * D, ptr(ws['sig']), ptr(self._f32('w1')), 8, ptr(ws['arg']),
+             ptr(ws['dzs']), ptr(ws['dw_part']), B, D, 4, self.dt)
+        for i, k in enumerate(self.WIRING):
+            col, c = cols[k]
+            call('vqa_colsum', ptr(ws['dw_part'][:, i]), 4, ptr(self._g(f'w{i + 1}')), B, 1, _lib.F32)
+            call('vqa_colsum', ptr(ws['dzs'][:, i]), 4 * D, ptr(self._g(f'dim_chg_gap{k}.0.bias')), B, D, self.dt)
+            self._wgrad(ws['dzs'][:, i], 4 * D, ws['gmeanT'][:, col:], Ct, f'dim_chg_gap{k}.0.weight', D, c, B)
+        self._bucket_done('dim_chg_gap4.0.weight')
