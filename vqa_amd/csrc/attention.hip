@@ -391,6 +391,14 @@ k_attn_fwd_pipe(const bf16_t* __restrict__ P, int ldP, const bf16_t* __restrict_
     }
     __syncthreads();
 
+    // the first 8 rows of this thread's pooling column are requested now, so that HBM stays busy
+    // under the softmax (row indices clamped: every load is unconditional)
+    const bool pool = grp < G;
+    const bf16_t* col = Vb + (pool ? cv : 0) * 8;
+    u32x4_t xc[8], xn[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) xc[u] = __builtin_bit_cast(u32x4_t, ld_stream(col + (size_t)min(grp + u * G, R - 1) * ldV));
+
     // ---- phase 2: softmax over regions ---------------------------------------------
     float mx = -INFINITY;
     for (int i = tid; i < R; i += ATT_THREADS) mx = fmaxf(mx, s_s[i]);
@@ -406,34 +414,29 @@ k_attn_fwd_pipe(const bf16_t* __restrict__ P, int ldP, const bf16_t* __restrict_
     }
     __syncthreads();
 
-    // ---- phase 3: pooling, 8 rows in flight per thread -------------------------------------
+    // ---- phase 3: pooling, two batches of 8 rows in flight per thread ---------------------------
+    // (the next batch is requested before the current one is consumed: the load queue never drains)
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (grp < G) {
-        const bf16_t* col = Vb + cv * 8;
-        int rr = grp;
-        for (; rr + 7 * G < R; rr += 8 * G) {
-            u32x4_t x[8];
+    for (int rr = grp; rr < R; rr += 8 * G) {
+        if (rr + 8 * G < R) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) x[u] = __builtin_bit_cast(u32x4_t, ld_stream(col + (size_t)(rr + u * G) * ldV));
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const float w = w_s[rr + u * G];
-#pragma unroll
-                for (int h = 0; h < 4; ++h) {
-                    acc[2 * h] = fmaf(w, bf16_lo(x[u][h]), acc[2 * h]);
-                    acc[2 * h + 1] = fmaf(w, bf16_hi(x[u][h]), acc[2 * h + 1]);
-                }
-            }
+            for (int u = 0; u < 8; ++u)
+                xn[u] = __builtin_bit_cast(u32x4_t, ld_stream(col + (size_t)min(rr + (8 + u) * G, R - 1) * ldV));
         }
-        for (; rr < R; rr += G) {
-            const u32x4_t x = __builtin_bit_cast(u32x4_t, ld_stream(col + (size_t)rr * ldV));
-            const float w = w_s[rr];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int row = rr + u * G;
+            const float w = row < R ? w_s[row] : 0.f;
 #pragma unroll
             for (int h = 0; h < 4; ++h) {
-                acc[2 * h] = fmaf(w, bf16_lo(x[h]), acc[2 * h]);
-                acc[2 * h + 1] = fmaf(w, bf16_hi(x[h]), acc[2 * h + 1]);
+                acc[2 * h] = fmaf(w, bf16_lo(xc[u][h]), acc[2 * h]);
+                acc[2 * h + 1] = fmaf(w, bf16_hi(xc[u][h]), acc[2 * h + 1]);
             }
         }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) xc[u] = xn[u];
+    }
+    if (pool) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) red[(size_t)(grp * nv + cv) * 8 + e] = acc[e];
     }
