@@ -569,17 +569,22 @@ k_attn_bwd_pipe(const bf16_t* __restrict__ P, int ldP, const bf16_t* __restrict_
             for (int e = 0; e < 8; ++e) ov[e] = f32_to_bf16(o[e]);
             __builtin_nontemporal_store(ov, reinterpret_cast<u16x8*>(colD + (size_t)r * ld_dP));
         };
-        int r = grp;
-        for (; r + 3 * G < R; r += 4 * G) {
-            u32x4_t x[4];
+        // two batches of 4 rows in flight: the next batch is requested before the current one is consumed
+        // (row indices clamped, so every load is unconditional; rows past R are not consumed)
+        u32x4_t xc[4], xn[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) x[u] = __builtin_bit_cast(u32x4_t, ld_stream(colP + (size_t)(r + u * G) * ldP));
+        for (int u = 0; u < 4; ++u) xc[u] = __builtin_bit_cast(u32x4_t, ld_stream(colP + (size_t)min(grp + u * G, R - 1) * ldP));
+        for (int r = grp; r < R; r += 4 * G) {
+            if (r + 4 * G < R) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) body(x[u], r + u * G);
-        }
-        for (; r < R; r += G) {
-            const u32x4_t x = __builtin_bit_cast(u32x4_t, ld_stream(colP + (size_t)r * ldP));
-            body(x, r);
+                for (int u = 0; u < 4; ++u)
+                    xn[u] = __builtin_bit_cast(u32x4_t, ld_stream(colP + (size_t)min(r + (4 + u) * G, R - 1) * ldP));
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (r + u * G < R) body(xc[u], r + u * G);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) xc[u] = xn[u];
         }
     }
     // fixed-order reduction over the G row groups: dqa, then dwa = sum ds - 2 sum ds r
