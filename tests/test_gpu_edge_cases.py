@@ -1,0 +1,88 @@
+"""Odd shapes through the whole step (fp32, against the oracle): a single sample, a single token, a single
+region, every question all-pad, maximum-length questions, tiny class counts, an empty batch, region counts
+and widths that are not multiples of the kernels' tile sizes."""
+import pytest
+import torch
+
+from oracle import vqa_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_err(got, ref):
+    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+    return float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+
+
+def _run(kw, B, R, L, hops=1, tokens=None, train=True):
+    from vqa_amd.model import VQAAttnModel
+    p = vqa_ref.init_params(seed=11, hops=hops, **kw)
+    m = VQAAttnModel(['w'] * kw['vq'], ['a'] * kw['C'], None, dtype=torch.float32, emb_size=kw['E'], question_out=kw['Hq'],
+                     visual_out=kw['Dv'], attention_dim=kw['A'], fusion_in=kw['F'], fusion_hidden=kw['Hf'], hops=hops,
+                     seed=77)
+    m.load_state_dict(p)
+    m = m.to('cuda').train(train)
+    b = vqa_ref.synthetic_batch(B, R, kw['Dv'], max(L, 3), kw['vq'], kw['C'], seed=B * 100 + R + L)
+    if L < 3:                           # the synthetic generator draws lengths from {3..L}
+        b['tokens'] = torch.randint(0, kw['vq'] + 1, (B, L), generator=torch.Generator().manual_seed(B + L))
+    if tokens is not None:
+        b['tokens'] = tokens
+    seeds = [vqa_ref.site_seed(77, 1, s) for s in range(6)] if train else None
+    lref, loss_ref, gref = vqa_ref.loss_and_grads(p, b['feats'], b['tokens'], b['answers'], None, hops, drop_seeds=seeds)
+    _, _, g64 = vqa_ref.loss_and_grads({k: v.double() for k, v in p.items()}, b['feats'].double(), b['tokens'],
+                                       b['answers'], None, hops, drop_seeds=seeds)
+    logits = m(b['feats'].cuda(), b['tokens'].cuda())
+    assert logits.shape == (B, kw['C'])
+    assert rel_err(logits, lref) <= 1e-5
+    torch.nn.functional.cross_entropy(logits, b['answers'].cuda()).backward()
+    named = dict(m.named_parameters())
+    for k in gref:
+        if k.endswith('linear_a.bias') or float(g64[k].abs().max()) < 1e-12:
+            continue                    # R = 1: the softmax is constant and the attention parameters get zero gradient
+        noise = rel_err(gref[k], g64[k])
+        assert rel_err(named[k].grad, g64[k]) <= max(2e-5, 4 * noise), (k, rel_err(named[k].grad, g64[k]), noise)
+    return m
+
+
+KW = dict(vq=40, C=13, E=20, Hq=40, Dv=72, A=24, F=40, Hf=16)
+
+
+@pytest.mark.parametrize('B,R,L,hops', [(1, 9, 7, 1), (2, 1, 5, 1), (3, 7, 1, 1), (1, 1, 1, 2), (5, 197, 3, 1),
+                                        (67, 3, 20, 2), (130, 50, 14, 1)])
+def test_odd_shapes(B, R, L, hops):
+    _run(KW, B, R, L, hops)
+
+
+def test_every_question_all_pad_or_full_length():
+    L = 9
+    tok = torch.zeros((6, L), dtype=torch.long)
+    tok[1::2] = torch.randint(1, KW['vq'] + 1, (3, L), generator=torch.Generator().manual_seed(1))   # no trailing pad at all
+    _run(KW, 6, 11, L, tokens=tok)
+    _run(KW, 4, 5, L, tokens=torch.zeros((4, L), dtype=torch.long), train=False)
+
+
+def test_minimal_widths():
+    _run(dict(vq=3, C=2, E=8, Hq=8, Dv=8, A=8, F=8, Hf=8), 4, 4, 4)
+
+
+def test_empty_batch_returns_empty_logits():
+    from vqa_amd.model import VQAAttnModel
+    kw = KW
+    m = VQAAttnModel(['w'] * kw['vq'], ['a'] * kw['C'], None, dtype=torch.float32, emb_size=kw['E'], question_out=kw['Hq'],
+                     visual_out=kw['Dv'], attention_dim=kw['A'], fusion_in=kw['F'], fusion_hidden=kw['Hf']).to('cuda').eval()
+    out = m(torch.zeros((0, 5, kw['Dv']), device='cuda'), torch.zeros((0, 7), dtype=torch.long, device='cuda'))
+    assert out.shape == (0, kw['C'])
+
+
+def test_rejected_inputs_raise():
+    from vqa_amd import _lib
+    from vqa_amd.model import VQAAttnModel
+    kw = KW
+    m = VQAAttnModel(['w'] * kw['vq'], ['a'] * kw['C'], None, dtype=torch.float32, emb_size=kw['E'], question_out=kw['Hq'],
+                     visual_out=kw['Dv'], attention_dim=kw['A'], fusion_in=kw['F'], fusion_hidden=kw['Hf']).to('cuda')
+    with pytest.raises(_lib.VqaHipError):                       # no CPU path
+        m(torch.zeros((2, 5, kw['Dv'])), torch.zeros((2, 7), dtype=torch.long))
+    with pytest.raises(ValueError):                             # wrong feature width
+        m(torch.zeros((2, 5, kw['Dv'] + 8), device='cuda'), torch.zeros((2, 7), dtype=torch.long, device='cuda'))
+    with pytest.raises(ValueError):                             # batch mismatch
+        m(torch.zeros((2, 5, kw['Dv']), device='cuda'), torch.zeros((3, 7), dtype=torch.long, device='cuda'))

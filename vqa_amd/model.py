@@ -398,6 +398,8 @@ class _VQAHeadModel(nn.Module):
 
     def forward(self, input_v, input_q, captions=None):
         feats, tokens, captions = self._prepare_inputs(input_v, input_q, captions)
+        if tokens.shape[0] == 0:                     # empty batch: nothing to launch
+            return torch.zeros((0, self.num_classes), dtype=torch.float32, device=tokens.device)
         self._materialize(tokens.device)
         params = [p for _, p in self._trainable_order()]
         if torch.is_grad_enabled() and any(p.requires_grad for p in params):
