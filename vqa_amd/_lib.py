@@ -29,6 +29,7 @@ _SIGNATURES = {
     'vqa_lstm_cell_packed': [_p, _i, _z, _p, _i, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p, _p, _i, _p],
     'vqa_lstm_cell_bwd_packed': [_p, _i, _z, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     'vqa_embedding_grad': [_p, _i, _z, _i, _p, _p, _p, _i, _p, _i, _i, _i, _p],
+    'vqa_colsum_multi': [_p, _i, _p],
     'vqa_colsum_rows': [_p, _i, _p, _p, _i, _i, _p],
     'vqa_caption_pool': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     'vqa_inv_norm': [_p, _p, _l, _i, _i, _i, _p],
@@ -119,6 +120,20 @@ def call(name: str, *args):
     if rc != 0:
         raise VqaHipError(f'{name} failed ({rc}): {lib.vqa_last_error_string().decode()}')
     return rc
+
+
+class ColsumDesc(C.Structure):
+    """VqaColsumDesc of include/vqa_hip.h."""
+    _fields_ = [('X', C.c_void_p), ('ld', C.c_int), ('M', C.c_int), ('N', C.c_int), ('dtype', C.c_int),
+                ('out', C.c_void_p), ('out2', C.c_void_p)]
+
+
+def colsum_multi(problems):
+    """problems: iterable of (X, ld, M, N, dtype, out, out2-or-None) with tensors for X / out / out2."""
+    arr = (ColsumDesc * len(problems))()
+    for d, (X, ld, M, N, dt, out, out2) in zip(arr, problems):
+        d.X, d.ld, d.M, d.N, d.dtype, d.out, d.out2 = ptr(X), ld, M, N, dt, ptr(out), ptr(out2)
+    return call('vqa_colsum_multi', arr, len(problems))
 
 
 def dtype_code(dt: torch.dtype) -> int:

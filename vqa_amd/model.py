@@ -548,20 +548,21 @@ class _VQAHeadModel(nn.Module):
         g = self._g
         # classifier
         self._wgrad(ws['dlogits'], Cp, ws['h1d'], Hf, 'linear_classif2.weight', C, Hf, B)
-        call('vqa_colsum', ptr(ws['dlogits']), Cp, ptr(g('linear_classif2.bias')), B, C, dt)
         slab, sk, st = self._gemm_slabs(ws['dlogits'], Cp, 1, self._w('linear_classif2.weight'), Hf, 0, B, Hf, C)
         call('vqa_tanh_dropout_bwd', ptr(slab), sk, st, ptr(ws['h1t']), Hf, ptr(ws['dz1']), Hf, B, Hf, seeds[3], p, dt)
         self._wgrad(ws['dz1'], Hf, ws['x'], F + Ec, 'linear_classif1.weight', Hf, F + Ec, B)
-        call('vqa_colsum', ptr(ws['dz1']), Hf, ptr(g('linear_classif1.bias')), B, Hf, dt)
-        self._bucket_done('linear_classif1.bias')
         # fusion
         slab, sk, st = self._gemm_slabs(ws['dz1'], Hf, 1, self._w('linear_classif1.weight'), F + Ec, 0, B, F + Ec, Hf)
         call('vqa_fusion_bwd', ptr(slab), sk, st, F + Ec, ptr(ws['xv']), ptr(ws['xq']), ptr(ws['dzv']), ptr(ws['dzq']),
              F, B, F, seeds[2], p, dt)
+        # the four bias gradients of the head in one launch
+        _lib.colsum_multi([(ws['dlogits'], Cp, B, C, dt, g('linear_classif2.bias'), None),
+                           (ws['dz1'], Hf, B, Hf, dt, g('linear_classif1.bias'), None),
+                           (ws['dzv'], F, B, F, dt, g('linear_v.bias'), None),
+                           (ws['dzq'], F, B, F, dt, g('linear_q.bias'), None)])
+        self._bucket_done('linear_classif1.bias')
         self._wgrad(ws['dzv'], F, ws['pooled_d'], Dv, 'linear_v.weight', F, Dv, B)
-        call('vqa_colsum', ptr(ws['dzv']), F, ptr(g('linear_v.bias')), B, F, dt)
         self._wgrad(ws['dzq'], F, ws['q_d'], H, 'linear_q.weight', F, H, B)
-        call('vqa_colsum', ptr(ws['dzq']), F, ptr(g('linear_q.bias')), B, F, dt)
         self._bucket_done('linear_q.bias')
         slab, sk, st = self._gemm_slabs(ws['dzv'], F, 1, self._w('linear_v.weight'), Dv, 0, B, Dv, F)
         call('vqa_epilogue', ptr(slab), sk, st, B, Dv, None, None, None, 0, 0, None, 0, ptr(ws['d_pooled']), Dv,
@@ -859,10 +860,10 @@ class VQAAttnModel(_VQAHeadModel):
                  ptr(self._f32(pre + 'linear_a.weight')), ptr(ws['inv_norm']), ptr(ws[f'p{k}']), ptr(ws['d_pooled']), Dv,
                  ptr(ws['dP']), A, ptr(ws['dqa32']), ptr(ws['dqaT']), A, ptr(ws['dwa_part']), ptr(ws['dc_part']),
                  B, R, A, Dv, dt)
-            call('vqa_colsum', ptr(ws['dwa_part']), A, ptr(g(pre + 'linear_a.weight')), B, A, _lib.F32)
-            call('vqa_sum_scale', ptr(ws['dc_part']), ptr(g(pre + 'linear_a.bias')), B, 1.0)
-            call('vqa_colsum', ptr(ws['dqa32']), A, ptr(g(pre + 'linear_qa.bias')), B, A, _lib.F32)
-            call('vqa_colsum', ptr(ws['dqa32']), A, ptr(g(pre + 'linear_va.bias')), B, A, _lib.F32)
+            # the hop's small gradients in one launch: w_a, its offset c, and the two biases that share d(P + qa)
+            _lib.colsum_multi([(ws['dwa_part'], A, B, A, _lib.F32, g(pre + 'linear_a.weight'), None),
+                               (ws['dc_part'], 1, B, 1, _lib.F32, g(pre + 'linear_a.bias'), None),
+                               (ws['dqa32'], A, B, A, _lib.F32, g(pre + 'linear_qa.bias'), g(pre + 'linear_va.bias'))])
             self._wgrad(ws['dqaT'], A, uT, H, pre + 'linear_qa.weight', A, H, B)
             if k > 0:
                 ppre = f'attention.{k - 1}.'
