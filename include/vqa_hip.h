@@ -82,8 +82,10 @@ int vqa_embedding_gather_packed(const int64_t* tokens, const void* table, void* 
 int vqa_lstm_cell_packed(const float* slabs, int nslab, size_t slab_stride, const void* xg, int ld_xg, float* c,
                          void* h, int ld_h, const int32_t* lengths, float* q_f32, void* q_t, int ld_q,
                          int B, int H, int t, int L, const int32_t* perm, const int32_t* active,
-                         const int32_t* offsets, void* hs, int ld_hs, void* gates_out, float* c_out, int dtype,
-                         hipStream_t stream);
+                         const int32_t* offsets, void* hs, int ld_hs, void* gates_out, float* c_out, void* q_drop,
+                         unsigned drop_seed, float drop_p, int dtype, hipStream_t stream);
+/* (q_drop, optional, leading dimension ld_q: dropout(q_t) with the mask of vqa_dropout on a (B, H) matrix --
+ *  dropoutQ / dropoutV of model.py:67, 151 fused into the producer of the question vector) */
 /* (gates_out (packed rows x 4H, activated i, f, g, o) and c_out (packed rows x H, fp32), optional and
  *  together: the state saved for backward through time) */
 
@@ -121,7 +123,10 @@ int vqa_inv_norm(const void* V, float* inv_norm, long rows, int Dv, int ldV, int
 size_t vqa_attn_lds_bytes(int R, int A, int Dv);
 int vqa_attn_fwd(const void* P, int ldP, const void* V, int ldV, const float* qa, int ld_qa, const float* w_a,
                  const float* c_a, const float* inv_norm, float* p_out, void* pooled_t, float* pooled_f32,
-                 int ld_pool, int B, int R, int A, int Dv, int dtype, hipStream_t stream);
+                 int ld_pool, int B, int R, int A, int Dv, int dtype, void* pooled_drop, unsigned drop_seed,
+                 float drop_p, hipStream_t stream);
+/* (pooled_drop, optional: dropout(pooled_t) with the mask of vqa_dropout on a (B, Dv) matrix -- dropoutV of
+ *  model.py:62 fused into the producer) */
 /* Backward of the above: dP is written pre-multiplied by inv_norm (so dW_va = dP^T V),
  * dqa[b,:] = sum_r dP_unscaled, dwa_part[b,:] and dc_part[b] are per-sample partials. */
 int vqa_attn_bwd(const void* P, int ldP, const void* V, int ldV, const float* qa, int ld_qa, const float* w_a,

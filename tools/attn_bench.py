@@ -16,7 +16,7 @@ dpool = torch.randn(B, Dv, device='cuda', generator=g); dP = torch.zeros(B * R, 
 dqa = torch.zeros(B, A, device='cuda'); dqaT = torch.zeros(B, A, device='cuda', dtype=dt)
 dwa = torch.zeros(B, A, device='cuda'); dc = torch.zeros(B, device='cuda')
 def fwd(i):
-    call('vqa_attn_fwd', ptr(Ps[i % n_rot]), A, ptr(Vs[i % n_rot]), Dv, ptr(qa), A, ptr(wa), ptr(c), ptr(inv), ptr(p), ptr(pooled), None, Dv, B, R, A, Dv, BF16)
+    call('vqa_attn_fwd', ptr(Ps[i % n_rot]), A, ptr(Vs[i % n_rot]), Dv, ptr(qa), A, ptr(wa), ptr(c), ptr(inv), ptr(p), ptr(pooled), None, Dv, B, R, A, Dv, BF16, None, 0, 0.0)
 def bwd(i):
     call('vqa_attn_bwd', ptr(Ps[i % n_rot]), A, ptr(Vs[i % n_rot]), Dv, ptr(qa), A, ptr(wa), ptr(inv), ptr(p), ptr(dpool), Dv, ptr(dP), A, ptr(dqa), ptr(dqaT), A, ptr(dwa), ptr(dc), B, R, A, Dv, BF16)
 def inv_norm(i):

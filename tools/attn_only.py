@@ -22,7 +22,7 @@ dwa = torch.zeros(B, A, device='cuda'); dc = torch.zeros(B, device='cuda')
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 9
 for i in range(n):
     P, V = Ps[i % n_rot], Vs[i % n_rot]
-    call('vqa_attn_fwd', ptr(P), A, ptr(V), Dv, ptr(qa), A, ptr(wa), ptr(c), ptr(inv), ptr(p), ptr(pooled), None, Dv, B, R, A, Dv, BF16)
+    call('vqa_attn_fwd', ptr(P), A, ptr(V), Dv, ptr(qa), A, ptr(wa), ptr(c), ptr(inv), ptr(p), ptr(pooled), None, Dv, B, R, A, Dv, BF16, None, 0, 0.0)
     call('vqa_attn_bwd', ptr(P), A, ptr(V), Dv, ptr(qa), A, ptr(wa), ptr(inv), ptr(p), ptr(dpool), Dv, ptr(dP), A, ptr(dqa), ptr(dqaT), A, ptr(dwa), ptr(dc), B, R, A, Dv, BF16)
 torch.cuda.synchronize()
 print('done')

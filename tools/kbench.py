@@ -36,7 +36,7 @@ def main():
     res['inv_norm'] = timeit(lambda: call('vqa_inv_norm', ptr(feats), ptr(ws['inv_norm']), B * R, Dv, Dv, m.dt))
     pre = 'attention.0.'
     res['gemm_P(K4)'] = timeit(lambda: call('vqa_gemm_fused', ptr(feats), Dv, 1, ptr(m._w(pre + 'linear_va.weight')), Dv, 1, ptr(ws['P0']), A, B * R, A, Dv, ptr(m._f32(pre + 'linear_va.bias')), ptr(ws['inv_norm']), 0, m.dt, m.dt, 0))
-    res['attn_fwd'] = timeit(lambda: call('vqa_attn_fwd', ptr(ws['P0']), A, ptr(feats), Dv, ptr(ws['qa0']), A, ptr(m._f32(pre + 'linear_a.weight')), ptr(m._f32(pre + 'linear_a.bias')), ptr(ws['inv_norm']), ptr(ws['p0']), ptr(ws['pooled0']), None, Dv, B, R, A, Dv, m.dt))
+    res['attn_fwd'] = timeit(lambda: call('vqa_attn_fwd', ptr(ws['P0']), A, ptr(feats), Dv, ptr(ws['qa0']), A, ptr(m._f32(pre + 'linear_a.weight')), ptr(m._f32(pre + 'linear_a.bias')), ptr(ws['inv_norm']), ptr(ws['p0']), ptr(ws['pooled0']), None, Dv, B, R, A, Dv, m.dt, None, 0, 0.0))
     res['attn_bwd'] = timeit(lambda: call('vqa_attn_bwd', ptr(ws['P0']), A, ptr(feats), Dv, ptr(ws['qa0']), A, ptr(m._f32(pre + 'linear_a.weight')), ptr(ws['inv_norm']), ptr(ws['p0']), ptr(ws['d_pooled']), Dv, ptr(ws['dP']), A, ptr(ws['dqa32']), ptr(ws['dqaT']), A, ptr(ws['dwa_part']), ptr(ws['dc_part']), B, R, A, Dv, m.dt))
     res['wgrad_Wva'] = timeit(lambda: m._wgrad(ws['dP'], A, feats, Dv, pre + 'linear_va.weight', A, Dv, B * R))
     res['lstm_step_gemm'] = timeit(lambda: m._gemm_slabs(ws['h'], H, 1, m._whh_t, H, 1, B, 4 * H, H))

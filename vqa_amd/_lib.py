@@ -26,7 +26,7 @@ _SIGNATURES = {
     'vqa_lstm_cell': [_p, _i, _z, _p, _i, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     'vqa_sequence_pack': [_p, _i, _i, _p, _p, _p, _p, _p],
     'vqa_embedding_gather_packed': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _i, _p, _i, _p],
-    'vqa_lstm_cell_packed': [_p, _i, _z, _p, _i, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p, _p, _i, _p],
+    'vqa_lstm_cell_packed': [_p, _i, _z, _p, _i, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p, _p, _p, _u, _f, _i, _p],
     'vqa_lstm_cell_bwd_packed': [_p, _i, _z, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     'vqa_embedding_grad': [_p, _i, _z, _i, _p, _p, _p, _i, _p, _i, _i, _i, _p],
     'vqa_colsum_multi': [_p, _i, _p],
@@ -42,7 +42,7 @@ _SIGNATURES = {
     'vqa_flatten_cm': [_p, _i, _p, _i, _i, _i, _i, _u, _f, _i, _p],
     'vqa_unflatten_cm': [_p, _i, _p, _i, _i, _i, _i, _i, _p],
     'vqa_attn_lds_bytes': [_i, _i, _i],
-    'vqa_attn_fwd': [_p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    'vqa_attn_fwd': [_p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _u, _f, _p],
     'vqa_attn_bwd': [_p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _i, _p, _i, _p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _p],
     'vqa_gemm_splitk_hint': [_i, _i, _i, _i, _i],
     'vqa_gemm_slabs': [_p, _i, _i, _p, _i, _i, _p, _z, _i, _i, _i, _i, _i, _i, _i, _p],

@@ -25,7 +25,8 @@ __global__ void __launch_bounds__(ATT_THREADS)
 k_attn_fwd(const T* __restrict__ P, int ldP, const T* __restrict__ V, int ldV, const float* __restrict__ qa,
            int ld_qa, const float* __restrict__ w_a, const float* __restrict__ c_a,
            const float* __restrict__ inv_norm, float* __restrict__ p_out, T* __restrict__ pooled_t,
-           float* __restrict__ pooled_f32, int ld_pool, int R, int A, int Dv) {
+           float* __restrict__ pooled_f32, int ld_pool, int R, int A, int Dv,
+           T* __restrict__ pooled_drop, unsigned seed, unsigned thr, float dscale) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* qa_s = smem;
     float* wa_s = qa_s + A;
@@ -134,7 +135,10 @@ k_attn_fwd(const T* __restrict__ P, int ldP, const T* __restrict__ V, int ldV, c
             float s = 0.f;
             for (int g = 0; g < G; ++g) s += red[(size_t)g * Dv + d];
             if (pooled_f32) pooled_f32[(size_t)b * ld_pool + d] = s;
-            if (pooled_t) pooled_t[(size_t)b * ld_pool + d] = from_f32<T>(s);
+            const T st = from_f32<T>(s);
+            if (pooled_t) pooled_t[(size_t)b * ld_pool + d] = st;
+            if (pooled_drop)
+                pooled_drop[(size_t)b * ld_pool + d] = from_f32<T>(to_f32<T>(st) * drop_mult(seed, (unsigned)(b * Dv + d), thr, dscale));
         }
     } else {
         // very wide features: each thread walks its vector columns over all rows
@@ -150,7 +154,11 @@ k_attn_fwd(const T* __restrict__ P, int ldP, const T* __restrict__ V, int ldV, c
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 if (pooled_f32) pooled_f32[(size_t)b * ld_pool + c * 8 + i] = acc[i];
-                if (pooled_t) pooled_t[(size_t)b * ld_pool + c * 8 + i] = from_f32<T>(acc[i]);
+                const T st = from_f32<T>(acc[i]);
+                if (pooled_t) pooled_t[(size_t)b * ld_pool + c * 8 + i] = st;
+                if (pooled_drop)
+                    pooled_drop[(size_t)b * ld_pool + c * 8 + i] =
+                        from_f32<T>(to_f32<T>(st) * drop_mult(seed, (unsigned)(b * Dv + c * 8 + i), thr, dscale));
             }
         }
     }
@@ -322,7 +330,8 @@ __global__ void __launch_bounds__(ATT_THREADS)
 k_attn_fwd_pipe(const bf16_t* __restrict__ P, int ldP, const bf16_t* __restrict__ V, int ldV,
                 const float* __restrict__ qa, int ld_qa, const float* __restrict__ w_a,
                 const float* __restrict__ c_a, const float* __restrict__ inv_norm, float* __restrict__ p_out,
-                bf16_t* __restrict__ pooled_t, float* __restrict__ pooled_f32, int ld_pool, int R, int A, int Dv) {
+                bf16_t* __restrict__ pooled_t, float* __restrict__ pooled_f32, int ld_pool, int R, int A, int Dv,
+                bf16_t* __restrict__ pooled_drop, unsigned seed, unsigned thr, float dscale) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_s = smem;
     float* w_s = s_s + ((R + 3) & ~3);
@@ -445,7 +454,10 @@ k_attn_fwd_pipe(const bf16_t* __restrict__ P, int ldP, const bf16_t* __restrict_
         float s = 0.f;
         for (int g = 0; g < G; ++g) s += red[(size_t)g * Dv + d];
         if (pooled_f32) pooled_f32[(size_t)b * ld_pool + d] = s;
-        if (pooled_t) pooled_t[(size_t)b * ld_pool + d] = f32_to_bf16(s);
+        const bf16_t st = f32_to_bf16(s);
+        if (pooled_t) pooled_t[(size_t)b * ld_pool + d] = st;
+        if (pooled_drop)
+            pooled_drop[(size_t)b * ld_pool + d] = f32_to_bf16(bf16_to_f32(st) * drop_mult(seed, (unsigned)(b * Dv + d), thr, dscale));
     }
 }
 
@@ -632,8 +644,12 @@ static int attn_check(int B, int R, int A, int Dv, int ldP, int ldV) {
 
 int vqa_attn_fwd(const void* P, int ldP, const void* V, int ldV, const float* qa, int ld_qa, const float* w_a,
                  const float* c_a, const float* inv_norm, float* p_out, void* pooled_t, float* pooled_f32,
-                 int ld_pool, int B, int R, int A, int Dv, int dtype, hipStream_t stream) {
+                 int ld_pool, int B, int R, int A, int Dv, int dtype, void* pooled_drop, unsigned drop_seed,
+                 float drop_p, hipStream_t stream) {
     VQA_REQUIRE(P && V && qa && w_a && c_a && inv_norm && p_out && (pooled_t || pooled_f32), "vqa_attn_fwd: null pointer");
+    VQA_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "vqa_attn_fwd: drop_p must be in [0, 1)");
+    const unsigned thr = drop_threshold(drop_p);
+    const float dsc = 1.0f / (1.0f - drop_p);
     if (int rc = attn_check(B, R, A, Dv, ldP, ldV)) return rc;
     VQA_REQUIRE(ld_qa >= A && ld_pool >= Dv, "vqa_attn_fwd: ld_qa / ld_pool too small");
     if (B == 0) return 0;
@@ -646,7 +662,7 @@ int vqa_attn_fwd(const void* P, int ldP, const void* V, int ldV, const float* qa
     if (lds_p > 48 * 1024)                                                                                         \
         VQA_REQUIRE(hipFuncSetAttribute((const void*)k_attn_fwd_pipe<NVA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p) == hipSuccess, "vqa_attn_fwd: cannot reserve LDS"); \
     k_attn_fwd_pipe<NVA><<<B, ATT_THREADS, lds_p, stream>>>((const bf16_t*)P, ldP, (const bf16_t*)V, ldV, qa, \
-        ld_qa, w_a, c_a, inv_norm, p_out, (bf16_t*)pooled_t, pooled_f32, ld_pool, R, A, Dv);               \
+        ld_qa, w_a, c_a, inv_norm, p_out, (bf16_t*)pooled_t, pooled_f32, ld_pool, R, A, Dv, (bf16_t*)pooled_drop, drop_seed, thr, dsc); \
   }
         if (nva_l == 1) ATT_FWD_PIPE(1) else if (nva_l == 2) ATT_FWD_PIPE(2) else if (nva_l == 3) ATT_FWD_PIPE(3) else ATT_FWD_PIPE(4)
 #undef ATT_FWD_PIPE
@@ -655,11 +671,11 @@ int vqa_attn_fwd(const void* P, int ldP, const void* V, int ldV, const float* qa
     if (dtype == VQA_F32) {
         VQA_REQUIRE(hipFuncSetAttribute((const void*)k_attn_fwd<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess, "vqa_attn_fwd: cannot reserve LDS");
         k_attn_fwd<float><<<B, ATT_THREADS, lds, stream>>>((const float*)P, ldP, (const float*)V, ldV, qa, ld_qa, w_a, c_a,
-                                                          inv_norm, p_out, (float*)pooled_t, pooled_f32, ld_pool, R, A, Dv);
+                                                          inv_norm, p_out, (float*)pooled_t, pooled_f32, ld_pool, R, A, Dv, (float*)pooled_drop, drop_seed, thr, dsc);
     } else if (dtype == VQA_BF16) {
         VQA_REQUIRE(hipFuncSetAttribute((const void*)k_attn_fwd<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess, "vqa_attn_fwd: cannot reserve LDS");
         k_attn_fwd<bf16_t><<<B, ATT_THREADS, lds, stream>>>((const bf16_t*)P, ldP, (const bf16_t*)V, ldV, qa, ld_qa, w_a, c_a,
-                                                           inv_norm, p_out, (bf16_t*)pooled_t, pooled_f32, ld_pool, R, A, Dv);
+                                                           inv_norm, p_out, (bf16_t*)pooled_t, pooled_f32, ld_pool, R, A, Dv, (bf16_t*)pooled_drop, drop_seed, thr, dsc);
     } else return vqa_set_error(-22, "vqa_attn_fwd: dtype");
     return vqa_check_launch("vqa_attn_fwd");
 }

@@ -170,7 +170,8 @@ __global__ void __launch_bounds__(256) k_lstm_cell(const float* __restrict__ sla
                             float* __restrict__ q32, T* __restrict__ qT, int ld_q,
                             int B, int H, int t, int L, const int* __restrict__ perm,
                             const int* __restrict__ m_t, const int* __restrict__ offs,
-                            T* __restrict__ hs, int ld_hs, T* __restrict__ gates_out, float* __restrict__ cs_out) {
+                            T* __restrict__ hs, int ld_hs, T* __restrict__ gates_out, float* __restrict__ cs_out,
+                            T* __restrict__ q_drop, unsigned seed, unsigned thr, float dscale) {
     // packed mode (perm != null): state rows are in sorted order, only the first m_t[t] are live, their
     // input-projection rows start at row offs[t] of xg and q goes to the original row perm[b]
     const int H4 = H >> 2;
@@ -212,6 +213,13 @@ __global__ void __launch_bounds__(256) k_lstm_cell(const float* __restrict__ sla
         if (last == t) {
             Vec4<float>::store(q32 + (size_t)ob * ld_q + j, hn);
             Vec4<T>::store(qT + (size_t)ob * ld_q + j, hn);
+            if (q_drop) {                      // dropout of the stored (rounded) question vector, mask of a (B, H) matrix
+                f32x4 qd;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    qd[e] = to_f32<T>(from_f32<T>(hn[e])) * drop_mult(seed, (unsigned)(ob * H + j + e), thr, dscale);
+                Vec4<T>::store(q_drop + (size_t)ob * ld_q + j, qd);
+            }
         }
     }
 }
@@ -781,8 +789,8 @@ int vqa_embedding_gather_packed(const int64_t* tokens, const void* table, void* 
 int vqa_lstm_cell_packed(const float* slabs, int nslab, size_t slab_stride, const void* xg, int ld_xg, float* c,
                          void* h, int ld_h, const int32_t* lengths, float* q_f32, void* q_t, int ld_q,
                          int B, int H, int t, int L, const int32_t* perm, const int32_t* active,
-                         const int32_t* offsets, void* hs, int ld_hs, void* gates_out, float* c_out, int dtype,
-                         hipStream_t stream) {
+                         const int32_t* offsets, void* hs, int ld_hs, void* gates_out, float* c_out, void* q_drop,
+                         unsigned drop_seed, float drop_p, int dtype, hipStream_t stream) {
     VQA_REQUIRE(xg && c && h && lengths && q_f32 && q_t && perm && active && offsets && (nslab == 0 || slabs),
                 "vqa_lstm_cell_packed: null pointer");
     VQA_REQUIRE(B >= 0 && H > 0 && t >= 0 && t < L && ld_xg >= 4 * H && ld_h >= H && ld_q >= H, "vqa_lstm_cell_packed: bad sizes");
@@ -790,10 +798,13 @@ int vqa_lstm_cell_packed(const float* slabs, int nslab, size_t slab_stride, cons
                 "vqa_lstm_cell_packed: H and leading dimensions must be multiples of 4");
     VQA_REQUIRE(!hs || (ld_hs >= H && ld_hs % 4 == 0), "vqa_lstm_cell_packed: bad ld_hs");
     VQA_REQUIRE((gates_out == nullptr) == (c_out == nullptr), "vqa_lstm_cell_packed: gates_out and c_out go together");
+    VQA_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "vqa_lstm_cell_packed: drop_p must be in [0, 1)");
+    const unsigned thr = drop_threshold(drop_p);
+    const float dsc = 1.0f / (1.0f - drop_p);
     if (B == 0) return 0;
     DISPATCH_T(dtype, (k_lstm_cell<T><<<grid_for((long)B * (H / 4), 256), 256, 0, stream>>>(
         slabs, nslab, slab_stride, (const T*)xg, ld_xg, c, (T*)h, ld_h, lengths, q_f32, (T*)q_t, ld_q, B, H, t, L,
-        perm, active, offsets, (T*)hs, ld_hs, (T*)gates_out, c_out)));
+        perm, active, offsets, (T*)hs, ld_hs, (T*)gates_out, c_out, (T*)q_drop, drop_seed, thr, dsc)));
     return vqa_check_launch("vqa_lstm_cell_packed");
 }
 
@@ -807,7 +818,7 @@ int vqa_lstm_cell(const float* slabs, int nslab, size_t slab_stride, const void*
     if (B == 0) return 0;
     DISPATCH_T(dtype, (k_lstm_cell<T><<<grid_for((long)B * (H / 4), 256), 256, 0, stream>>>(
         slabs, nslab, slab_stride, (const T*)xg_t, ld_xg, c, (T*)h, ld_h, lengths, q_f32, (T*)q_t, ld_q, B, H, t, L,
-        nullptr, nullptr, nullptr, (T*)nullptr, 0, (T*)nullptr, nullptr)));
+        nullptr, nullptr, nullptr, (T*)nullptr, 0, (T*)nullptr, nullptr, (T*)nullptr, 0u, 0u, 1.0f)));
     return vqa_check_launch("vqa_lstm_cell");
 }
 

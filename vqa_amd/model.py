@@ -417,7 +417,7 @@ class _VQAHeadModel(nn.Module):
         self.drop_step += 1
         return tuple(site_seed(self.base_seed, self.drop_step, s) for s in range(6)), self.drop_p
 
-    def encode_question(self, tokens: torch.Tensor, ws=None, seeds=None) -> torch.Tensor:
+    def encode_question(self, tokens: torch.Tensor, ws=None, seeds=None, q_drop=None) -> torch.Tensor:
         """Embedding gather + LSTM layer(s) + last-valid-step selection -> q (B, Hq) fp32
         (seq2vec.py:40-45; with the '2-lstm' encoder seq2vec.py:61-76).  `seeds`: the two dropout seeds
         of the 2-lstm vectors in training mode."""
@@ -429,6 +429,7 @@ class _VQAHeadModel(nn.Module):
             ws = self._enc_workspace(B, L, dev)
         Ep, Hq, dt = _pad8(self.E), self.Hq, self.dt
         two = self.seq2vec.arch == '2-lstm'
+        fuse_drop = q_drop is not None and not two     # (buffer, seed, p): the head's dropout of q written by the cell kernel
         # packed sequences: rows sorted by length, so the rows still running at step t are the first
         # m_t[t] and their input projections are rows offs[t].. of xg; padding steps cost nothing
         call('vqa_sequence_pack', ptr(tokens), B, L, ptr(ws['len']), ptr(ws['perm']), ptr(ws['m_t']), ptr(ws['offs']))
@@ -455,7 +456,8 @@ class _VQAHeadModel(nn.Module):
                                                         active_rows=ws['m_t'].data_ptr() + 4 * t)
                 call('vqa_lstm_cell_packed', ptr(slab), sk, stride, ptr(ws['xg']), 4 * Hh, ptr(ws['c']), ptr(ws['h']), Hh,
                      ptr(ws['len']), q32, qT, Hq, B, Hh, t, L, ptr(ws['perm']), ptr(ws['m_t']),
-                     ptr(ws['offs']), ptr(hs), Hh, ptr(gates), ptr(cs), dt)
+                     ptr(ws['offs']), ptr(hs), Hh, ptr(gates), ptr(cs),
+                     ptr(q_drop[0]) if fuse_drop else None, q_drop[1] if fuse_drop else 0, q_drop[2] if fuse_drop else 0.0, dt)
             x, kin = hs, Hh
         if two and self.training and self.seq2vec_dropout > 0.0 and seeds is not None:
             Hh = Hq // 2
@@ -511,12 +513,13 @@ class _VQAHeadModel(nn.Module):
         if self.train_encoder:
             self._finish_pending()               # the deferred bucket holds the encoder's own weights
             self._frozen_key = None              # they change every step: refresh the operand copies
-        self.encode_question(tokens, ws, seeds[4:6])
+        self.encode_question(tokens, ws, seeds[4:6], q_drop=(ws['q_d'], seeds[1], p))
         self._visual_prologue(ws, feats, B)
         self._finish_pending()
         self._refresh_shadow()
         self._visual_forward(ws, feats, B, seeds[0], p)           # -> ws['pooled_d'] = dropout(visual vector)
-        call('vqa_dropout', ptr(ws['qT']), H, ptr(ws['q_d']), H, B, H, seeds[1], p, dt)
+        if self.seq2vec.arch == '2-lstm':       # (the single-layer encoder's cell kernel wrote q_d already)
+            call('vqa_dropout', ptr(ws['qT']), H, ptr(ws['q_d']), H, B, H, seeds[1], p, dt)
         self._linear(ws['pooled_d'], Dv, 'linear_v.weight', 'linear_v.bias', B, F, Dv, act=1, out_pre=ws['xv'], ld_pre=F)
         self._linear(ws['q_d'], H, 'linear_q.weight', 'linear_q.bias', B, F, H, act=1, out_pre=ws['xq'], ld_pre=F)
         call('vqa_fusion_fwd', ptr(ws['xv']), ptr(ws['xq']), ptr(ws['x']), F + Ec, B, F, seeds[2], p, dt)
@@ -837,15 +840,14 @@ class VQAAttnModel(_VQAHeadModel):
             ev = self._event_pair('attn_fwd')
             call('vqa_attn_fwd', ptr(ws[f'P{k}']), A, ptr(feats), Dv, ptr(ws[f'qa{k}']), A,
                  ptr(self._f32(pre + 'linear_a.weight')), ptr(self._f32(pre + 'linear_a.bias')), ptr(ws['inv_norm']),
-                 ptr(ws[f'p{k}']), ptr(ws[f'pooled{k}']), None, Dv, B, R, A, Dv, dt)
+                 ptr(ws[f'p{k}']), ptr(ws[f'pooled{k}']), None, Dv, B, R, A, Dv, dt,
+                 ptr(ws['pooled_d']) if k + 1 == self.hops else None, seed, p)       # dropoutV fused into the last hop
             if ev is not None:
                 ev[1].record()
             if k + 1 < self.hops:
                 self._linear(ws[f'pooled{k}'], Dv, pre + 'linear_u.weight', pre + 'linear_u.bias', B, H, Dv,
                              addend=u32, ld_add=H, out_pre=ws[f'u32_{k + 1}'], ld_pre=H, out_post=ws[f'uT_{k + 1}'], ld_post=H)
                 u32, uT = ws[f'u32_{k + 1}'], ws[f'uT_{k + 1}']
-        pooled = ws[f'pooled{self.hops - 1}']
-        call('vqa_dropout', ptr(pooled), Dv, ptr(ws['pooled_d']), Dv, B, Dv, seed, p, dt)
 
     def _visual_backward(self, ws, feats, B):
         R = feats.shape[1]
