@@ -223,9 +223,10 @@ int vqa_tanh_dropout_bwd(const float* slabs, int nslab, size_t slab_stride, cons
 /* out[n] = sum_m X[m,n] (bias gradients), fixed summation order */
 int vqa_colsum(const void* X, int ld, float* out, int M, int N, int dtype, hipStream_t stream);
 /* up to VQA_COLSUM_MAX such sums in one launch (the bias gradients of a backward pass); out2 (optional)
- * receives the same sums (two biases added to the same pre-activation share their gradient) */
+ * receives the same sums (two biases added to the same pre-activation share their gradient); every sum is
+ * multiplied by scale (1 for a gradient, 1/B for the mean of the per-row losses) */
 #define VQA_COLSUM_MAX 8
-typedef struct VqaColsumDesc { const void* X; int ld; int M; int N; int dtype; float* out; float* out2; } VqaColsumDesc;
+typedef struct VqaColsumDesc { const void* X; int ld; int M; int N; int dtype; float scale; float* out; float* out2; } VqaColsumDesc;
 int vqa_colsum_multi(const VqaColsumDesc* descs, int n, hipStream_t stream);
 /* the same over the first *rows rows (a device-side count) */
 int vqa_colsum_rows(const void* X, int ld, float* out, const int32_t* rows, int N, int dtype, hipStream_t stream);

@@ -125,14 +125,16 @@ def call(name: str, *args):
 class ColsumDesc(C.Structure):
     """VqaColsumDesc of include/vqa_hip.h."""
     _fields_ = [('X', C.c_void_p), ('ld', C.c_int), ('M', C.c_int), ('N', C.c_int), ('dtype', C.c_int),
-                ('out', C.c_void_p), ('out2', C.c_void_p)]
+                ('scale', C.c_float), ('out', C.c_void_p), ('out2', C.c_void_p)]
 
 
 def colsum_multi(problems):
-    """problems: iterable of (X, ld, M, N, dtype, out, out2-or-None) with tensors for X / out / out2."""
+    """problems: iterable of (X, ld, M, N, dtype, out, out2-or-None[, scale]) with tensors for X / out / out2."""
     arr = (ColsumDesc * len(problems))()
-    for d, (X, ld, M, N, dt, out, out2) in zip(arr, problems):
+    for d, pr in zip(arr, problems):
+        X, ld, M, N, dt, out, out2 = pr[:7]
         d.X, d.ld, d.M, d.N, d.dtype, d.out, d.out2 = ptr(X), ld, M, N, dt, ptr(out), ptr(out2)
+        d.scale = pr[7] if len(pr) > 7 else 1.0
     return call('vqa_colsum_multi', arr, len(problems))
 
 

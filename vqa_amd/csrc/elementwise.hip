@@ -461,6 +461,7 @@ __global__ void __launch_bounds__(256) k_colsum_multi(ColsumBatch batch) {
         float s = 0.f;
 #pragma unroll
         for (int g = 0; g < 8; ++g) s += part[g][cx];
+        s *= d.scale;
         d.out[n] = s;
         if (d.out2) d.out2[n] = s;
     }

@@ -180,6 +180,7 @@ class _VQAHeadModel(nn.Module):
         self.kernel_events = None     # set to {} to collect per-kernel HIP event pairs
         self._pending = None          # last gradient bucket of the previous train_step still in flight
         self._bptt = False            # the running forward keeps the encoder state for backward through time
+        self._loss_pending = False    # the mean of the per-row losses is still to be reduced (by backward)
 
     # ------------------------------------------------------------------ flat parameter storage
     def _trainable_order(self) -> List[Tuple[str, nn.Parameter]]:
@@ -558,8 +559,10 @@ class _VQAHeadModel(nn.Module):
         slab, sk, st = self._gemm_slabs(ws['dz1'], Hf, 1, self._w('linear_classif1.weight'), F + Ec, 0, B, F + Ec, Hf)
         call('vqa_fusion_bwd', ptr(slab), sk, st, F + Ec, ptr(ws['xv']), ptr(ws['xq']), ptr(ws['dzv']), ptr(ws['dzq']),
              F, B, F, seeds[2], p, dt)
-        # the four bias gradients of the head in one launch
-        _lib.colsum_multi([(ws['dlogits'], Cp, B, C, dt, g('linear_classif2.bias'), None),
+        # the four bias gradients of the head (and the mean of the per-row losses) in one launch
+        extra = [(ws['loss_rows'], 1, B, 1, _lib.F32, ws['loss'], None, 1.0 / B)] if self._loss_pending else []
+        self._loss_pending = False
+        _lib.colsum_multi(extra + [(ws['dlogits'], Cp, B, C, dt, g('linear_classif2.bias'), None),
                            (ws['dz1'], Hf, B, Hf, dt, g('linear_classif1.bias'), None),
                            (ws['dzv'], F, B, F, dt, g('linear_v.bias'), None),
                            (ws['dzq'], F, B, F, dt, g('linear_q.bias'), None)])
@@ -631,7 +634,7 @@ class _VQAHeadModel(nn.Module):
         self._bucket_done('seq2vec.embedding.weight')
 
     # ------------------------------------------------------------------ loss / prediction / step
-    def loss_and_grad_logits(self, answers: torch.Tensor) -> torch.Tensor:
+    def loss_and_grad_logits(self, answers: torch.Tensor, reduce: bool = True) -> torch.Tensor:
         """Fused softmax cross-entropy (mean) of the last forward + its gradient into the
         backward workspace.  Returns the 1-element device tensor holding the loss."""
         ws, feats, B, L, seeds, p = self._ctx
@@ -640,7 +643,9 @@ class _VQAHeadModel(nn.Module):
         _lib.bind_stream()
         call('vqa_softmax_ce', ptr(ws['logits']), Cp, ptr(ans), ptr(ws['loss_rows']), ptr(ws['dlogits']), Cp, B, C,
              1.0 / B, self.dt)
-        call('vqa_sum_scale', ptr(ws['loss_rows']), ptr(ws['loss']), B, 1.0 / B)
+        if reduce:                      # (train_step folds this mean into the backward pass's batched column sums)
+            call('vqa_sum_scale', ptr(ws['loss_rows']), ptr(ws['loss']), B, 1.0 / B)
+        self._loss_pending = not reduce
         return ws['loss']
 
     def predict(self, logits: Optional[torch.Tensor] = None, answers=None, type_ids=None, counters=None, n_types: int = 4):
@@ -700,7 +705,7 @@ class _VQAHeadModel(nn.Module):
         with torch.no_grad():
             self._bptt = True
             self._forward_impl(feats, tokens, captions)
-            loss = self.loss_and_grad_logits(answers)
+            loss = self.loss_and_grad_logits(answers, reduce=False)
             if reducer is not None:
                 reducer.begin(self)
                 self.grad_ready_hook = reducer.bucket_ready
