@@ -222,6 +222,11 @@ int vqa_tanh_dropout_bwd(const float* slabs, int nslab, size_t slab_stride, cons
 
 /* out[n] = sum_m X[m,n] (bias gradients), fixed summation order */
 int vqa_colsum(const void* X, int ld, float* out, int M, int N, int dtype, hipStream_t stream);
+/* up to VQA_SLABSUM_MAX split-K reductions in one launch: out[e] = sum_s slabs[s * slab_stride + e], e < count
+ * (the weight gradients of a bucket, reduced together once their products are done) */
+#define VQA_SLABSUM_MAX 8
+typedef struct VqaSlabSumDesc { const float* slabs; int nslab; size_t slab_stride; long count; float* out; } VqaSlabSumDesc;
+int vqa_slab_sum_multi(const VqaSlabSumDesc* descs, int n, hipStream_t stream);
 /* up to VQA_COLSUM_MAX such sums in one launch (the bias gradients of a backward pass); out2 (optional)
  * receives the same sums (two biases added to the same pre-activation share their gradient); every sum is
  * multiplied by scale (1 for a gradient, 1/B for the mean of the per-row losses) */

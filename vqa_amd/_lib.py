@@ -30,6 +30,7 @@ _SIGNATURES = {
     'vqa_lstm_cell_bwd_packed': [_p, _i, _z, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     'vqa_embedding_grad': [_p, _i, _z, _i, _p, _p, _p, _i, _p, _i, _i, _i, _p],
     'vqa_colsum_multi': [_p, _i, _p],
+    'vqa_slab_sum_multi': [_p, _i, _p],
     'vqa_colsum_rows': [_p, _i, _p, _p, _i, _i, _p],
     'vqa_caption_pool': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     'vqa_inv_norm': [_p, _p, _l, _i, _i, _i, _p],
@@ -136,6 +137,20 @@ def colsum_multi(problems):
         d.X, d.ld, d.M, d.N, d.dtype, d.out, d.out2 = ptr(X), ld, M, N, dt, ptr(out), ptr(out2)
         d.scale = pr[7] if len(pr) > 7 else 1.0
     return call('vqa_colsum_multi', arr, len(problems))
+
+
+class SlabSumDesc(C.Structure):
+    """VqaSlabSumDesc of include/vqa_hip.h."""
+    _fields_ = [('slabs', C.c_void_p), ('nslab', C.c_int), ('slab_stride', C.c_size_t), ('count', C.c_long),
+                ('out', C.c_void_p)]
+
+
+def slab_sum_multi(problems):
+    """problems: iterable of (slab address, nslab, stride, count, out tensor)."""
+    arr = (SlabSumDesc * len(problems))()
+    for d, (slabs, nslab, stride, count, out) in zip(arr, problems):
+        d.slabs, d.nslab, d.slab_stride, d.count, d.out = slabs, nslab, stride, count, ptr(out)
+    return call('vqa_slab_sum_multi', arr, len(problems))
 
 
 def dtype_code(dt: torch.dtype) -> int:

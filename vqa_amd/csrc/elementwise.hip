@@ -426,6 +426,30 @@ __global__ void __launch_bounds__(256) k_colsum(const T* __restrict__ X, int ld,
     }
 }
 
+// several split-K reductions in one launch: out_i[e] = sum_s slabs_i[s * stride_i + e], e < count_i (count_i % 4 == 0
+// is not required; 16-byte accesses are used when the slab and the output allow it)
+struct SlabSumBatch { VqaSlabSumDesc d[VQA_SLABSUM_MAX]; int first_block[VQA_SLABSUM_MAX + 1]; int n; };
+
+__global__ void __launch_bounds__(256) k_slab_sum_multi(SlabSumBatch batch) {
+    int pi = 0;
+    while (pi + 1 < batch.n && (int)blockIdx.x >= batch.first_block[pi + 1]) ++pi;
+    const VqaSlabSumDesc d = batch.d[pi];
+    const long i4 = ((long)((int)blockIdx.x - batch.first_block[pi]) * 256 + threadIdx.x) * 4;
+    if (i4 >= d.count) return;
+    const bool vec = i4 + 4 <= d.count && (d.slab_stride & 3) == 0 && ((((uintptr_t)d.slabs) | ((uintptr_t)d.out)) & 15) == 0;
+    if (vec) {
+        f32x4 a = *reinterpret_cast<const f32x4*>(d.slabs + i4);
+        for (int s = 1; s < d.nslab; ++s) a += *reinterpret_cast<const f32x4*>(d.slabs + s * d.slab_stride + i4);
+        *reinterpret_cast<f32x4*>(d.out + i4) = a;
+    } else {
+        for (long i = i4; i < d.count && i < i4 + 4; ++i) {
+            float a = 0.f;
+            for (int s = 0; s < d.nslab; ++s) a += d.slabs[s * d.slab_stride + i];
+            d.out[i] = a;
+        }
+    }
+}
+
 // several column sums in one launch: problem i sums the M_i rows of X_i (fp32 or bf16) into out_i (and out2_i)
 struct ColsumBatch { VqaColsumDesc d[VQA_COLSUM_MAX]; int first_block[VQA_COLSUM_MAX + 1]; int n; };
 
@@ -911,6 +935,24 @@ int vqa_colsum(const void* X, int ld, float* out, int M, int N, int dtype, hipSt
     VQA_REQUIRE(X && out && M >= 0 && N > 0 && ld >= N, "vqa_colsum: bad arguments");
     DISPATCH_T(dtype, (k_colsum<T><<<(N + 31) / 32, 256, 0, stream>>>((const T*)X, ld, out, M, N)));
     return vqa_check_launch("vqa_colsum");
+}
+
+int vqa_slab_sum_multi(const VqaSlabSumDesc* descs, int n, hipStream_t stream) {
+    VQA_REQUIRE(descs && n >= 1 && n <= VQA_SLABSUM_MAX, "vqa_slab_sum_multi: 1..8 problems");
+    SlabSumBatch batch;
+    batch.n = n;
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        const VqaSlabSumDesc& d = descs[i];
+        VQA_REQUIRE(d.slabs && d.out && d.nslab >= 1 && d.count > 0 && (d.nslab == 1 || d.slab_stride >= (size_t)d.count),
+                    "vqa_slab_sum_multi: bad problem");
+        batch.d[i] = d;
+        batch.first_block[i] = blocks;
+        blocks += (int)((d.count + 1023) / 1024);
+    }
+    batch.first_block[n] = blocks;
+    k_slab_sum_multi<<<blocks, 256, 0, stream>>>(batch);
+    return vqa_check_launch("vqa_slab_sum_multi");
 }
 
 int vqa_colsum_multi(const VqaColsumDesc* descs, int n, hipStream_t stream) {

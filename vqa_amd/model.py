@@ -181,6 +181,7 @@ class _VQAHeadModel(nn.Module):
         self._pending = None          # last gradient bucket of the previous train_step still in flight
         self._bptt = False            # the running forward keeps the encoder state for backward through time
         self._loss_pending = False    # the mean of the per-row losses is still to be reduced (by backward)
+        self._wslab, self._wslab_off, self._wgrad_pending = None, 0, []
 
     # ------------------------------------------------------------------ flat parameter storage
     def _trainable_order(self) -> List[Tuple[str, nn.Parameter]]:
@@ -240,7 +241,7 @@ class _VQAHeadModel(nn.Module):
         # bucket boundaries (element ranges of the flat buffer) in completion order
         names = [n for n, _ in order]
         enc = [self._encoder_trainable_order()[0][0]] if self.train_encoder else []
-        cuts = sorted({names.index(n) for n in ['linear_v.weight'] + self._visual_bucket_starts() + enc})
+        cuts = sorted({names.index(n) for n in self._visual_bucket_starts() + enc})
         starts = [0] + [offsets[c][0] for c in cuts]
         ends = starts[1:] + [total]
         self.buckets = [(s, e) for s, e in zip(starts, ends) if e > s]
@@ -359,11 +360,36 @@ class _VQAHeadModel(nn.Module):
              ptr(addend), ld_add, act, ptr(out_pre), ld_pre, ptr(out_post), ld_post,
              self.dt if post_dtype is None else post_dtype, seed, p)
 
-    def _wgrad(self, dy, ld_dy, x, ldx, wname, M, N, K, active_k=None):
-        """grad(W)[M,N] = dy^T x with dy stored [K][M], x stored [K][N]."""
+    def _wgrad(self, dy, ld_dy, x, ldx, wname, M, N, K, active_k=None, defer=False):
+        """grad(W)[M,N] = dy^T x with dy stored [K][M], x stored [K][N].  defer: the split-K partial sums go to
+        an arena of their own and are reduced later, together with the other deferred ones, by _flush_wgrads()."""
+        if defer:
+            sk = call('vqa_gemm_splitk_hint', M, N, K, 0, 0)
+            stride = M * N
+            addr = self._arena(sk * stride, dy.device)
+            call('vqa_gemm_slabs_rows', ptr(dy), ld_dy, 0, ptr(x), ldx, 0, addr, stride, N, M, N, K, sk,
+                 self.dt, self.gemm_engine, None, active_k)
+            self._wgrad_pending.append((addr, sk, stride, stride, self._g(wname)))
+            return
         slab, sk, stride = self._gemm_slabs(dy, ld_dy, 0, x, ldx, 0, M, N, K, active_k=active_k)
         call('vqa_epilogue', ptr(slab), sk, stride, M, N, None, None, None, 0, 0, ptr(self._g(wname)), N,
              None, 0, _lib.F32, 0, 0.0)
+
+    def _arena(self, nfloats: int, device) -> int:
+        """Address of nfloats floats that stay untouched until _flush_wgrads()."""
+        if self._wslab is None or self._wslab.device != device or self._wslab_off + nfloats > self._wslab.numel():
+            self._flush_wgrads()
+            if self._wslab is None or self._wslab.device != device or nfloats > self._wslab.numel():
+                self._wslab = torch.empty(max(2 * nfloats, 16 << 20), dtype=torch.float32, device=device)
+        addr = self._wslab.data_ptr() + 4 * self._wslab_off
+        self._wslab_off += (nfloats + 63) // 64 * 64
+        return addr
+
+    def _flush_wgrads(self):
+        """Reduce the deferred weight-gradient partial sums into the flat gradient buffer, 8 per launch."""
+        pend, self._wgrad_pending, self._wslab_off = self._wgrad_pending, [], 0
+        for i in range(0, len(pend), 8):
+            _lib.slab_sum_multi(pend[i:i + 8])
 
     def _bucket_done(self, name: str):
         if self.grad_ready_hook is not None:
@@ -551,10 +577,10 @@ class _VQAHeadModel(nn.Module):
         _lib.bind_stream()
         g = self._g
         # classifier
-        self._wgrad(ws['dlogits'], Cp, ws['h1d'], Hf, 'linear_classif2.weight', C, Hf, B)
+        self._wgrad(ws['dlogits'], Cp, ws['h1d'], Hf, 'linear_classif2.weight', C, Hf, B, defer=True)
         slab, sk, st = self._gemm_slabs(ws['dlogits'], Cp, 1, self._w('linear_classif2.weight'), Hf, 0, B, Hf, C)
         call('vqa_tanh_dropout_bwd', ptr(slab), sk, st, ptr(ws['h1t']), Hf, ptr(ws['dz1']), Hf, B, Hf, seeds[3], p, dt)
-        self._wgrad(ws['dz1'], Hf, ws['x'], F + Ec, 'linear_classif1.weight', Hf, F + Ec, B)
+        self._wgrad(ws['dz1'], Hf, ws['x'], F + Ec, 'linear_classif1.weight', Hf, F + Ec, B, defer=True)
         # fusion
         slab, sk, st = self._gemm_slabs(ws['dz1'], Hf, 1, self._w('linear_classif1.weight'), F + Ec, 0, B, F + Ec, Hf)
         call('vqa_fusion_bwd', ptr(slab), sk, st, F + Ec, ptr(ws['xv']), ptr(ws['xq']), ptr(ws['dzv']), ptr(ws['dzq']),
@@ -566,9 +592,9 @@ class _VQAHeadModel(nn.Module):
                            (ws['dz1'], Hf, B, Hf, dt, g('linear_classif1.bias'), None),
                            (ws['dzv'], F, B, F, dt, g('linear_v.bias'), None),
                            (ws['dzq'], F, B, F, dt, g('linear_q.bias'), None)])
-        self._bucket_done('linear_classif1.bias')
-        self._wgrad(ws['dzv'], F, ws['pooled_d'], Dv, 'linear_v.weight', F, Dv, B)
-        self._wgrad(ws['dzq'], F, ws['q_d'], H, 'linear_q.weight', F, H, B)
+        self._wgrad(ws['dzv'], F, ws['pooled_d'], Dv, 'linear_v.weight', F, Dv, B, defer=True)
+        self._wgrad(ws['dzq'], F, ws['q_d'], H, 'linear_q.weight', F, H, B, defer=True)
+        self._flush_wgrads()                      # the head's four weight gradients reduced in one launch
         self._bucket_done('linear_q.bias')
         slab, sk, st = self._gemm_slabs(ws['dzv'], F, 1, self._w('linear_v.weight'), Dv, 0, B, Dv, F)
         call('vqa_epilogue', ptr(slab), sk, st, B, Dv, None, None, None, 0, 0, None, 0, ptr(ws['d_pooled']), Dv,
@@ -763,6 +789,7 @@ class _VQAHeadModel(nn.Module):
         self._frozen_key = None
         self._ws.clear()
         self._slab = None
+        self._wslab, self._wslab_off, self._wgrad_pending = None, 0, []
         return out
 
     def load_state_dict(self, state_dict, strict: bool = True, **kw):

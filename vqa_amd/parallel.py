@@ -4,7 +4,7 @@ The reference has no multi-GPU path (its run_1.sh starts unrelated runs on
 different --gpu ids); data parallelism over the batch is exact here because
 every op of the step treats samples independently and the loss is a mean.
 Each rank computes gradients of its local-mean loss into the model's flat
-gradient buffer; the buckets of that buffer (classifier, fusion, attention
+gradient buffer; the buckets of that buffer (classifier + fusion head, attention
 small terms, image projection -- the order backward completes them) are
 sum-all-reduced as soon as they are complete, overlapping the rest of
 backward, and the 1/world factor is folded into the Adam kernel's gradient
