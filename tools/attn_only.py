@@ -15,6 +15,7 @@ wa = torch.randn(A, device='cuda', generator=g) * 0.03
 c = torch.zeros(1, device='cuda')
 inv = torch.rand(B * R, device='cuda', generator=g) * 0.05
 p = torch.zeros(B, R, device='cuda'); pooled = torch.zeros(B, Dv, device='cuda', dtype=dt)
+pooled_d = torch.zeros(B, Dv, device='cuda', dtype=dt)
 dpool = torch.randn(B, Dv, device='cuda', generator=g)
 dP = torch.zeros(B * R, A, device='cuda', dtype=dt)
 dqa = torch.zeros(B, A, device='cuda'); dqaT = torch.zeros(B, A, device='cuda', dtype=dt)
@@ -22,7 +23,7 @@ dwa = torch.zeros(B, A, device='cuda'); dc = torch.zeros(B, device='cuda')
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 9
 for i in range(n):
     P, V = Ps[i % n_rot], Vs[i % n_rot]
-    call('vqa_attn_fwd', ptr(P), A, ptr(V), Dv, ptr(qa), A, ptr(wa), ptr(c), ptr(inv), ptr(p), ptr(pooled), None, Dv, B, R, A, Dv, BF16, None, 0, 0.0)
+    call('vqa_attn_fwd', ptr(P), A, ptr(V), Dv, ptr(qa), A, ptr(wa), ptr(c), ptr(inv), ptr(p), ptr(pooled), None, Dv, B, R, A, Dv, BF16, ptr(pooled_d), 1234, 0.5)
     call('vqa_attn_bwd', ptr(P), A, ptr(V), Dv, ptr(qa), A, ptr(wa), ptr(inv), ptr(p), ptr(dpool), Dv, ptr(dP), A, ptr(dqa), ptr(dqaT), A, ptr(dwa), ptr(dc), B, R, A, Dv, BF16)
 torch.cuda.synchronize()
 print('done')
