@@ -13,7 +13,7 @@ import torch
 
 F32, BF16 = 0, 1
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libvqa_hip.so')
+LIB_PATH = os.environ.get('VQA_HIP_LIB', os.path.join(_HERE, 'libvqa_hip.so'))   # (override: A/B of kernel builds)
 
 _p, _i, _l, _f, _u, _z = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_uint, C.c_size_t
 

@@ -312,6 +312,51 @@ __global__ void __launch_bounds__(256) k_inv_norm(const T* __restrict__ V, float
     }
 }
 
+// bf16 rows of up to 2048 elements: raw 16-byte nontemporal loads (the norm pass is the first touch of the
+// features in a step and nothing of a row is reused by it), four rows in flight per wave
+__device__ __forceinline__ float sumsq_bf16x8(const u16x8& v) {
+    float a = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const float x = bf16_to_f32(v[e]); a = fmaf(x, x, a); }
+    return a;
+}
+
+template <int NV>      // 16-byte vectors per lane and row = ceil(Dv / 512)
+__global__ void __launch_bounds__(256) k_inv_norm_stream(const bf16_t* __restrict__ V, float* __restrict__ inv_norm,
+                                                         long rows, int Dv, int ldV) {
+    const int lane = threadIdx.x & 63;
+    const long nw = (long)gridDim.x * 4, w0 = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nv = Dv >> 3;
+    int voff[NV];
+    float live[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { const int v = lane + 64 * i; voff[i] = min(v, nv - 1) * 8; live[i] = v < nv ? 1.f : 0.f; }
+    constexpr int D = 4;                                   // rows in flight
+    u16x8 buf[D][NV];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        const long r = min(w0 + d * nw, rows - 1);
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            buf[d][i] = __builtin_nontemporal_load(reinterpret_cast<const u16x8*>(V + (size_t)r * ldV + voff[i]));
+    }
+    for (long row = w0; row < rows; row += D * nw) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const long r = row + d * nw;
+            float ss = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) ss += sumsq_bf16x8(buf[d][i]) * live[i];
+            const long rn = min(r + D * nw, rows - 1);     // refill this slot before the reduction waits
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+                buf[d][i] = __builtin_nontemporal_load(reinterpret_cast<const u16x8*>(V + (size_t)rn * ldV + voff[i]));
+            ss = wave_sum(ss);
+            if (lane == 0 && r < rows) inv_norm[r] = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // generic split-K reduce + epilogue
 //   v = act(row_scale[m] * sum_s slab[s][m][n] + bias[n] + addend[m][n])
@@ -861,7 +906,16 @@ int vqa_inv_norm(const void* V, float* inv_norm, long rows, int Dv, int ldV, int
     VQA_REQUIRE(V && inv_norm && rows >= 0 && Dv > 0, "vqa_inv_norm: bad arguments");
     VQA_REQUIRE(Dv % 8 == 0 && ldV % 8 == 0 && ldV >= Dv, "vqa_inv_norm: Dv and ldV must be multiples of 8");
     if (rows == 0) return 0;
-    DISPATCH_T(dtype, (k_inv_norm<T><<<(unsigned)((rows + 3) / 4 < 2048 ? (rows + 3) / 4 : 2048), 256, 0, stream>>>((const T*)V, inv_norm, rows, Dv, ldV)));
+    const unsigned grid = (unsigned)((rows + 3) / 4 < 2048 ? (rows + 3) / 4 : 2048);
+    if (dtype == VQA_BF16 && Dv <= 2048) {
+        const int nvl = (Dv / 8 + 63) / 64;
+        if (nvl == 1) k_inv_norm_stream<1><<<grid, 256, 0, stream>>>((const bf16_t*)V, inv_norm, rows, Dv, ldV);
+        else if (nvl == 2) k_inv_norm_stream<2><<<grid, 256, 0, stream>>>((const bf16_t*)V, inv_norm, rows, Dv, ldV);
+        else if (nvl == 3) k_inv_norm_stream<3><<<grid, 256, 0, stream>>>((const bf16_t*)V, inv_norm, rows, Dv, ldV);
+        else k_inv_norm_stream<4><<<grid, 256, 0, stream>>>((const bf16_t*)V, inv_norm, rows, Dv, ldV);
+        return vqa_check_launch("vqa_inv_norm");
+    }
+    DISPATCH_T(dtype, (k_inv_norm<T><<<grid, 256, 0, stream>>>((const T*)V, inv_norm, rows, Dv, ldV)));
     return vqa_check_launch("vqa_inv_norm");
 }
 
