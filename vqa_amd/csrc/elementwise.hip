@@ -558,20 +558,46 @@ __global__ void __launch_bounds__(256) k_softmax_ce(const float* __restrict__ lo
     __shared__ float red[8];
     const int b = blockIdx.x;
     const float* z = logits + (size_t)b * ld;
+    // rows of up to 16 * 256 classes are read once and kept in registers; longer rows are re-read
+    constexpr int KEEP = 16;
+    const bool keep = C <= KEEP * 256;
+    float zr[KEEP];
     float mx = -INFINITY;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) mx = fmaxf(mx, z[c]);
+    if (keep) {
+#pragma unroll
+        for (int k = 0; k < KEEP; ++k) {
+            const int c = threadIdx.x + 256 * k;
+            zr[k] = c < C ? z[c] : -INFINITY;
+            mx = fmaxf(mx, zr[k]);
+        }
+    } else {
+        for (int c = threadIdx.x; c < C; c += blockDim.x) mx = fmaxf(mx, z[c]);
+    }
     mx = block_max(mx, red);
     float se = 0.f;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) se += expf(z[c] - mx);
+    if (keep) {
+#pragma unroll
+        for (int k = 0; k < KEEP; ++k) { zr[k] = expf(zr[k] - mx); se += zr[k]; }     // exp(-inf) = 0 past the row
+    } else {
+        for (int c = threadIdx.x; c < C; c += blockDim.x) se += expf(z[c] - mx);
+    }
     se = block_sum(se, red);
     const int64_t y = target[b];
     if (threadIdx.x == 0) loss_row[b] = (y >= 0 && y < C) ? (logf(se) - (z[y] - mx)) : 0.f;
     if (dlogits) {
         const float inv = 1.0f / se;
-        for (int c = threadIdx.x; c < ld_d; c += blockDim.x) {
-            float g = 0.f;
-            if (c < C) g = (expf(z[c] - mx) * inv - (c == y ? 1.f : 0.f)) * scale;
-            dlogits[(size_t)b * ld_d + c] = from_f32<T>(g);
+        if (keep) {
+#pragma unroll
+            for (int k = 0; k < KEEP; ++k) {
+                const int c = threadIdx.x + 256 * k;
+                if (c < ld_d) dlogits[(size_t)b * ld_d + c] = from_f32<T>(c < C ? (zr[k] * inv - (c == y ? 1.f : 0.f)) * scale : 0.f);
+            }
+        } else {
+            for (int c = threadIdx.x; c < ld_d; c += blockDim.x) {
+                float g = 0.f;
+                if (c < C) g = (expf(z[c] - mx) * inv - (c == y ? 1.f : 0.f)) * scale;
+                dlogits[(size_t)b * ld_d + c] = from_f32<T>(g);
+            }
         }
     }
 }
@@ -638,10 +664,12 @@ __global__ void __launch_bounds__(256) k_adam(float* __restrict__ p, const float
                                               float eps, float inv_bc1, float inv_sqrt_bc2, float grad_scale) {
     const long n4 = n >> 2;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        // gradients and moments are touched once per step: streamed past the caches; the parameters and
+        // their bf16 copies are what the next forward reads, so they go through them
         f32x4 pp = reinterpret_cast<f32x4*>(p)[i];
-        const f32x4 gg = reinterpret_cast<const f32x4*>(g)[i];
-        f32x4 mm = reinterpret_cast<f32x4*>(m)[i];
-        f32x4 vv = reinterpret_cast<f32x4*>(v)[i];
+        const f32x4 gg = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g) + i);
+        f32x4 mm = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(m) + i);
+        f32x4 vv = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(v) + i);
         u16x4 sh;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -653,8 +681,8 @@ __global__ void __launch_bounds__(256) k_adam(float* __restrict__ p, const float
             sh[k] = f32_to_bf16(pp[k]);
         }
         reinterpret_cast<f32x4*>(p)[i] = pp;
-        reinterpret_cast<f32x4*>(m)[i] = mm;
-        reinterpret_cast<f32x4*>(v)[i] = vv;
+        __builtin_nontemporal_store(mm, reinterpret_cast<f32x4*>(m) + i);
+        __builtin_nontemporal_store(vv, reinterpret_cast<f32x4*>(v) + i);
         if (shadow) reinterpret_cast<u16x4*>(shadow)[i] = sh;
     }
     // tail (n % 4 elements)
