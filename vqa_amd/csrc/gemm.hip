@@ -435,6 +435,7 @@ k_gemm_bf16_w8(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__
                 for (int j = 0; j < NT; ++j) fb[kk][j] = frag_read<BN, BKM>(lb, wn * 64 + j * 16, kk, lane);
             }
             __builtin_amdgcn_sched_barrier(0);     // all fragment reads are issued before the first MFMA
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
@@ -443,6 +444,7 @@ k_gemm_bf16_w8(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__
                     for (int j = 0; j < NT; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[kk][i], fb[kk][j], acc[i][j], 0, 0, 0);
             }
+            __builtin_amdgcn_s_setprio(0);
         } else {
             // 128 x 64 per wave: fragments of one K sub-step at a time (register budget)
 #pragma unroll
@@ -452,11 +454,13 @@ k_gemm_bf16_w8(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__
                 for (int i = 0; i < MT; ++i) fa[i] = frag_read<BM, AKM>(la, wm * WMR + i * 16, kk, lane);
 #pragma unroll
                 for (int j = 0; j < NT; ++j) fb[j] = frag_read<BN, BKM>(lb, wn * 64 + j * 16, kk, lane);
+                __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int j = 0; j < NT; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
             }
         }
     };
