@@ -570,6 +570,7 @@ k_gemm_bf16_r10(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict_
                 for (int i = 0; i < MT; ++i) fa[kk][i] = frag_read<128, AKM>(la, i * 16, kk, lane);
             }
             __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -577,6 +578,7 @@ k_gemm_bf16_r10(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict_
 #pragma unroll
                     for (int j = 0; j < NT; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[kk][i], fb[kk][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
         } else {
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
@@ -585,11 +587,13 @@ k_gemm_bf16_r10(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict_
                 for (int i = 0; i < MT; ++i) fa[i] = frag_read<128, AKM>(la, i * 16, kk, lane);
 #pragma unroll
                 for (int j = 0; j < NT; ++j) fb[j] = frag_read<128, BKM>(lb, bc + j * 16, kk, lane);
+                __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int j = 0; j < NT; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
             }
         }
     };
@@ -699,9 +703,9 @@ static inline int pick_tile(int M, int N, int K, int akm, int bkm, int engine) {
     // leave most CUs idle for a whole tile time, the smaller tile then fills the chip better
     const long b512 = t512 * split512, r512 = (b512 + 255) / 256 * 256, r256 = (t256 + 255) / 256 * 256;
     const bool ragged = akm && bkm && b512 < 1024 && b512 * 4 < r512 * 3 && t256 * r512 > b512 * r256;
-    // 256 x 256 tiles (the ten-quarter ring variant, engine 8 / 9, is 6-8 % faster at 8192^3 but not at this step's
-    // K = 2048 shapes, where it measured 1.5 % slower inside the step)
-    if (M >= 384 && N >= 192 && t512 >= 32 && t512 * split512 >= 192 && !ragged) return 512;
+    // 256 x 256 tiles; with both operands k-major the ten-quarter ring variant that reads a whole K tile's fragments
+    // before its MFMAs (engine 9) is the faster one: 6-8 % at 8192^3, 2 % on the image projection inside the step
+    if (M >= 384 && N >= 192 && t512 >= 32 && t512 * split512 >= 192 && !ragged) return (akm && bkm) ? 4096 : 512;
     if (akm && bkm && M >= 192 && N > 64 && t256 >= 40) return 256;   // 256 x 128 tiles, 3-stage ring
     return (M > 64 && N > 64 && t128 >= 40) ? 128 : 64;
 }
