@@ -145,7 +145,7 @@ def main():
                                    f'{L}-token questions, {C} answers, batch {B}/GPU, {args.hops} attention hop(s), '
                                    f'fwd+CE+bwd+all-reduce+Adam, dropout on',
                        'global_batch': world * B, 'parallelism': f'dp{world}'},
-            'roofline': {'bound': 'hbm', 'kernel': 'k_attn_fwd (fused attention forward)', 'achieved': achieved,
+            'roofline': {'bound': 'hbm', 'kernel': 'k_attn_fwd_online (fused attention forward)', 'achieved': achieved,
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'avg_launch_ms': k6_ms, 'algorithmic_bytes_per_launch': k6_bytes},
             'loss': float(loss),

@@ -15,6 +15,9 @@
 #define ATT_THREADS 1024
 #define ATT_WAVES (ATT_THREADS / 64)
 #define ATT_MAX_R 4096
+#ifndef ATT_ONLINE
+#define ATT_ONLINE 1
+#endif
 
 template <typename T> struct TanhSel { static __device__ __forceinline__ float f(float x) { return fast_tanh(x); } };
 template <> struct TanhSel<float> { static __device__ __forceinline__ float f(float x) { return tanhf(x); } };
@@ -461,6 +464,159 @@ k_attn_fwd_pipe(const bf16_t* __restrict__ P, int ldP, const bf16_t* __restrict_
     }
 }
 
+// Single-pass forward: scores and pooling advance together over chunks of 16 region rows (one row per wave),
+// with a running maximum (online softmax), so the P stream and the V stream are in flight all the time and
+// there is no idle phase between them.  Chunk k's rows are pooled while the scores of chunk k + 1 are computed;
+// one barrier per chunk publishes the scores.  Every thread keeps the same running maximum m (it is a function
+// of the published scores only), rescales its accumulators by exp(m_old - m_new), and its row group keeps a
+// partial sum of the exponentials; the groups are combined in a fixed order at the end.
+// Requirements (checked by the launcher): Dv / 8 <= 256 (at least 4 row groups), NVA <= 4.
+template <int NVA>
+__global__ void __launch_bounds__(ATT_THREADS)
+k_attn_fwd_online(const bf16_t* __restrict__ P, int ldP, const bf16_t* __restrict__ V, int ldV,
+                  const float* __restrict__ qa, int ld_qa, const float* __restrict__ w_a,
+                  const float* __restrict__ c_a, const float* __restrict__ inv_norm, float* __restrict__ p_out,
+                  bf16_t* __restrict__ pooled_t, float* __restrict__ pooled_f32, int ld_pool, int R, int A, int Dv,
+                  bf16_t* __restrict__ pooled_drop, unsigned seed, unsigned thr, float dscale) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int R4 = (R + 3) & ~3;
+    float* s_s = smem;                       // scores
+    float* wn_s = s_s + R4 + 16;             // inv_norm of the sample (+16: a chunk may read past R)
+    float* red = wn_s + R4 + 16;             // qa / w_a staging, then the cross-group combine
+    __shared__ float l_s[ATT_THREADS];         // one partial sum of exponentials per row group (up to one group per thread)
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    constexpr int CH = ATT_WAVES;            // rows per chunk
+
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const bf16_t* Pb = P + (size_t)b * R * ldP;
+    const bf16_t* Vb = V + (size_t)b * R * ldV;
+    const int nva = A >> 3, nv = Dv >> 3;
+    const int G = ATT_THREADS / nv, grp = tid / nv, cv = tid % nv;
+    const bool pool = grp < G;
+    const int nch = (R + CH - 1) / CH;
+
+    const float kk = 2.8853900817779268f;                 // 2 * log2(e)
+    for (int a = tid; a < A; a += ATT_THREADS) { red[a] = qa[(size_t)b * ld_qa + a] * kk; red[A + a] = 2.f * w_a[a]; }
+    for (int r = tid; r < R4 + 16; r += ATT_THREADS) {
+        wn_s[r] = r < R ? inv_norm[(size_t)b * R + r] : 0.f;
+        s_s[r] = -INFINITY;
+    }
+    __syncthreads();
+    float qk[NVA][8], w2[NVA][8];
+    float wsum = 0.f;
+    int voff[NVA];
+#pragma unroll
+    for (int i = 0; i < NVA; ++i) {
+        const int v = lane + 64 * i;
+        const int vc = min(v, nva - 1);
+        const float live = v < nva ? 1.f : 0.f;
+        voff[i] = vc * 8;
+        const f32x4 q0 = *reinterpret_cast<const f32x4*>(red + vc * 8), q1 = *reinterpret_cast<const f32x4*>(red + vc * 8 + 4);
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(red + A + vc * 8), g1 = *reinterpret_cast<const f32x4*>(red + A + vc * 8 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            qk[i][e] = q0[e]; qk[i][4 + e] = q1[e];
+            w2[i][e] = g0[e] * live; w2[i][4 + e] = g1[e] * live;
+            wsum += 0.5f * (w2[i][e] + w2[i][4 + e]);
+        }
+    }
+    wsum = wave_sum(wsum) + c_a[0];
+    __syncthreads();                                       // red is reused by the final combine
+
+    // row of this wave in chunk k: CH * k + wv; rows of this thread in chunk k: CH * k + grp + G * u, u < 4
+    auto load_p = [&](int k, u32x4_t (&dst)[NVA]) {
+        const bf16_t* row = Pb + (size_t)min(CH * k + wv, R - 1) * ldP;
+#pragma unroll
+        for (int i = 0; i < NVA; ++i) dst[i] = __builtin_bit_cast(u32x4_t, ld_stream(row + voff[i]));
+    };
+    const bf16_t* col = Vb + (pool ? cv : 0) * 8;
+    auto load_v = [&](int k, u32x4_t (&dst)[4]) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            dst[u] = __builtin_bit_cast(u32x4_t, ld_stream(col + (size_t)min(CH * k + grp + G * u, R - 1) * ldV));
+    };
+    auto score = [&](int k, const u32x4_t (&x)[NVA]) {
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < NVA; ++i)
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                const float y0 = fmaf(bf16_lo(x[i][h]), kk, qk[i][2 * h]);
+                const float y1 = fmaf(bf16_hi(x[i][h]), kk, qk[i][2 * h + 1]);
+                acc = fmaf(w2[i][2 * h], __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(y0) + 1.0f), acc);
+                acc = fmaf(w2[i][2 * h + 1], __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(y1) + 1.0f), acc);
+            }
+        acc = wave_sum(acc);
+        const int r = CH * k + wv;
+        if (lane == 0 && r < R) s_s[r] = wsum - acc;
+    };
+
+    // one chunk of P rows and one chunk of V rows are always in flight (16 x 2.4 KB + 16 x 4 KB per workgroup);
+    // a chunk takes several microseconds, so one chunk of look-ahead covers the HBM latency
+    u32x4_t pa[NVA];                                       // P row of the next chunk to score
+    u32x4_t va[4];                                         // V rows of the next chunk to pool
+    load_p(0, pa);
+    load_v(0, va);
+    score(0, pa);
+    load_p(1, pa);
+    __syncthreads();
+
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float m = -INFINITY, l = 0.f;
+    for (int k = 0; k < nch; ++k) {
+        if (k + 1 < nch) {                                 // scores of chunk k + 1, then request chunk k + 2
+            score(k + 1, pa);
+            load_p(k + 2, pa);
+        }
+        // pooling of chunk k under the running maximum
+        float mk = m;
+#pragma unroll
+        for (int j = 0; j < CH; ++j) mk = fmaxf(mk, s_s[CH * k + j]);        // entries past R hold -inf
+        const float scale = __expf(m - mk);                                   // exp(-inf) = 0 at k = 0
+        m = mk;
+        l *= scale;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] *= scale;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = grp + G * u;
+            const int row = CH * k + j;
+            const float e_r = (j < CH && row < R) ? __expf(s_s[row] - m) : 0.f;
+            l += e_r;
+            const float w = e_r * wn_s[min(row, R4 + 15)];
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                acc[2 * h] = fmaf(w, bf16_lo(va[u][h]), acc[2 * h]);
+                acc[2 * h + 1] = fmaf(w, bf16_hi(va[u][h]), acc[2 * h + 1]);
+            }
+        }
+        load_v(k + 1, va);
+        __syncthreads();                                   // publishes the scores of chunk k + 1
+    }
+
+    // combine the row groups in a fixed order; every group's partial sums share the final maximum m
+    if (pool) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[(size_t)(grp * nv + cv) * 8 + e] = acc[e];
+        if (cv == 0) l_s[grp] = l;
+    }
+    __syncthreads();
+    float lt = 0.f;
+    for (int g = 0; g < G; ++g) lt += l_s[g];
+    const float inv_l = 1.0f / lt;
+    for (int i = tid; i < R; i += ATT_THREADS) p_out[(size_t)b * R + i] = __expf(s_s[i] - m) * inv_l;
+    for (int d = tid; d < Dv; d += ATT_THREADS) {
+        float sacc = 0.f;
+        for (int g = 0; g < G; ++g) sacc += red[(size_t)g * Dv + d];
+        sacc *= inv_l;
+        if (pooled_f32) pooled_f32[(size_t)b * ld_pool + d] = sacc;
+        const bf16_t st = f32_to_bf16(sacc);
+        if (pooled_t) pooled_t[(size_t)b * ld_pool + d] = st;
+        if (pooled_drop)
+            pooled_drop[(size_t)b * ld_pool + d] = f32_to_bf16(bf16_to_f32(st) * drop_mult(seed, (unsigned)(b * Dv + d), thr, dscale));
+    }
+}
+
 // Backward, bf16, pipelined.  Same results layout as k_attn_bwd.  NVD = ceil(Dv / 512).
 // Phase C uses r = 1/(exp2(k (P+qa)) + 1):  t = 1 - 2r,  1 - t^2 = 4 r (1 - r).
 template <int NVD>
@@ -655,6 +811,21 @@ int vqa_attn_fwd(const void* P, int ldP, const void* V, int ldV, const float* qa
     if (B == 0) return 0;
     const size_t lds = ((size_t)2 * A + R + ((R + 3) & ~3) + (size_t)ATT_THREADS * 8) * sizeof(float);
     const int nva_l = (A / 8 + 63) / 64;
+    if (dtype == VQA_BF16 && Dv / 8 <= 256 && nva_l <= 4 && ATT_ONLINE) {
+        const size_t r4 = (size_t)((R + 3) & ~3);
+        const size_t fa = (size_t)2 * A, fc = (size_t)ATT_THREADS * 8;
+        const size_t lds_o = (2 * (r4 + 16) + (fa > fc ? fa : fc)) * sizeof(float);
+#define ATT_FWD_ONLINE(NVA)                                                                                        \
+  {                                                                                                                \
+    if (lds_o > 48 * 1024)                                                                                         \
+        VQA_REQUIRE(hipFuncSetAttribute((const void*)k_attn_fwd_online<NVA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_o) == hipSuccess, "vqa_attn_fwd: cannot reserve LDS"); \
+    k_attn_fwd_online<NVA><<<B, ATT_THREADS, lds_o, stream>>>((const bf16_t*)P, ldP, (const bf16_t*)V, ldV, qa, \
+        ld_qa, w_a, c_a, inv_norm, p_out, (bf16_t*)pooled_t, pooled_f32, ld_pool, R, A, Dv, (bf16_t*)pooled_drop, drop_seed, thr, dsc); \
+  }
+        if (nva_l == 1) ATT_FWD_ONLINE(1) else if (nva_l == 2) ATT_FWD_ONLINE(2) else if (nva_l == 3) ATT_FWD_ONLINE(3) else ATT_FWD_ONLINE(4)
+#undef ATT_FWD_ONLINE
+        return vqa_check_launch("vqa_attn_fwd");
+    }
     if (dtype == VQA_BF16 && Dv / 8 <= ATT_THREADS && nva_l <= 4) {
         const size_t lds_p = ((size_t)2 * ((R + 3) & ~3) + (size_t)ATT_THREADS * 8) * sizeof(float);
 #define ATT_FWD_PIPE(NVA)                                                                                          \
