@@ -195,7 +195,8 @@ __device__ __forceinline__ bf16x8_t frag_read(const char* lds, int r0, int kk, i
 
 // Accumulators -> global through LDS so that every store instruction writes whole 64..256-byte
 // row segments.  Each wave stages 32 rows of its (BM/2 x BN/2) tile at a time as fp32.
-template <int MT, int NT>
+// FS = distance in rows between a wave's consecutive 16-row fragments (16: one contiguous band).
+template <int MT, int NT, int FS = 16>
 __device__ __forceinline__ void epilogue_store(char* lds, f32x4 (&acc)[MT][NT], const Epi& epi, int split,
                                                int m_w, int n_w, int M, int N, int wave, int lane) {
     constexpr int WN = NT * 16, LDW = WN + 4;
@@ -216,7 +217,7 @@ __device__ __forceinline__ void epilogue_store(char* lds, f32x4 (&acc)[MT][NT], 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int rl = ii * 16 + (lane >> 4) * 4 + r;
-                const int m = m_w + pass * 32 + rl;
+                const int m = m_w + i * FS + (lane >> 4) * 4 + r;
                 const float rs = (epi.row_scale && m < M) ? epi.row_scale[m] : 1.f;
 #pragma unroll
                 for (int j = 0; j < NT; ++j) wl[rl * LDW + j * 16 + (lane & 15)] = epi.value(acc[i][j][r], rs, bias[j]);
@@ -230,7 +231,7 @@ __device__ __forceinline__ void epilogue_store(char* lds, f32x4 (&acc)[MT][NT], 
 #pragma unroll
             for (int it = 0; it < 32 * CPR / 64; ++it) {
                 const int q = it * 64 + lane, rl = q / CPR, c = (q % CPR) * 8;
-                const int m = m_w + pass * 32 + rl, n = n_w + c;
+                const int m = m_w + (pass * 2 + (rl >> 4)) * FS + (rl & 15), n = n_w + c;
                 if (m >= M || n >= N) continue;
                 const f32x4 a = *reinterpret_cast<const f32x4*>(wl + rl * LDW + c);
                 const f32x4 b = *reinterpret_cast<const f32x4*>(wl + rl * LDW + c + 4);
@@ -254,7 +255,7 @@ __device__ __forceinline__ void epilogue_store(char* lds, f32x4 (&acc)[MT][NT], 
 #pragma unroll
             for (int it = 0; it < 32 * CPR / 64; ++it) {
                 const int q = it * 64 + lane, rl = q / CPR, c = (q % CPR) * 4;
-                const int m = m_w + pass * 32 + rl, n = n_w + c;
+                const int m = m_w + (pass * 2 + (rl >> 4)) * FS + (rl & 15), n = n_w + c;
                 if (m >= M || n >= N) continue;
                 const f32x4 a = *reinterpret_cast<const f32x4*>(wl + rl * LDW + c);
                 float* dst = out + (size_t)m * epi.ld + n;
@@ -404,6 +405,14 @@ k_gemm_bf16_w8(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__
     const int kend = min(epi.kcap(K), kbeg + k_per_split);
     const int nk = kend > kbeg ? (kend - kbeg + GEMM_BK - 1) / GEMM_BK : 0;
     const int nfull = kend > kbeg ? (kend - kbeg) / GEMM_BK : 0;      // tiles [0, nfull) come by DMA
+    // BN = 128: a wave's four 16-row fragments are interleaved over the tile (fragment i of row-wave wm
+    // covers tile rows 16 (4 i + wm) ..), so that with a device-side row limit the live rows are spread
+    // evenly over the four SIMDs; fragments at or past the limit are neither multiplied nor stored.
+    constexpr bool IL = BN == 128;
+    constexpr int FS = IL ? 16 * WAVES_M : 16;
+    const int wrow = IL ? wm * 16 : wm * WMR;                         // tile row of this wave's fragment 0
+    const int mlim = epi.m_limit ? min(M, __builtin_amdgcn_readfirstlane(*epi.m_limit)) : M;
+    const int nl = IL ? max(0, min(MT, (mlim - m0 - wrow + FS - 1) / FS)) : MT;   // live fragments (a prefix)
 
     f32x4 acc[MT][NT];
 #pragma unroll
@@ -413,7 +422,7 @@ k_gemm_bf16_w8(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__
 
     const bf16_t* sa[NIA];
     const bf16_t* sb[NIB];
-    dma_setup<BM, AKM, NW>(A, lda, m0, M, wave, lane, sa);
+    dma_setup<BM, AKM, NW>(A, lda, m0, IL ? mlim : M, wave, lane, sa);   // rows past the limit re-read the last live row
     dma_setup<BN, BKM, NW>(B, ldb, n0, N, wave, lane, sb);
     const size_t ka = AKM ? 1 : (size_t)lda, kb = BKM ? 1 : (size_t)ldb;
 
@@ -430,7 +439,8 @@ k_gemm_bf16_w8(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
-                for (int i = 0; i < MT; ++i) fa[kk][i] = frag_read<BM, AKM>(la, wm * WMR + i * 16, kk, lane);
+                for (int i = 0; i < MT; ++i)
+                    if (!IL || i < nl) fa[kk][i] = frag_read<BM, AKM>(la, wrow + i * FS, kk, lane);
 #pragma unroll
                 for (int j = 0; j < NT; ++j) fb[kk][j] = frag_read<BN, BKM>(lb, wn * 64 + j * 16, kk, lane);
             }
@@ -440,9 +450,11 @@ k_gemm_bf16_w8(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__
             for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
+                    if (!IL || i < nl) {
 #pragma unroll
-                    for (int j = 0; j < NT; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[kk][i], fb[kk][j], acc[i][j], 0, 0, 0);
+                        for (int j = 0; j < NT; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[kk][i], fb[kk][j], acc[i][j], 0, 0, 0);
+                    }
             }
             __builtin_amdgcn_s_setprio(0);
         } else {
@@ -497,7 +509,7 @@ k_gemm_bf16_w8(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__
         compute(lds);
     }
     VMCNT_BARRIER(0);        // every wave is done with the ring before it becomes the store staging area
-    epilogue_store<MT, NT>(lds, acc, epi, split, m0 + wm * WMR, n0 + wn * 64, M, N, wave, lane);
+    epilogue_store<MT, NT, FS>(lds, acc, epi, split, m0 + wrow, n0 + wn * 64, IL ? mlim : M, N, wave, lane);
 }
 
 // ---- 256 x 256 tiles, ring of ten quarter-operand slots ------------------------------------
