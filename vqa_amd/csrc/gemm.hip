@@ -426,11 +426,32 @@ k_gemm_bf16_w8(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__
     dma_setup<BN, BKM, NW>(B, ldb, n0, N, wave, lane, sb);
     const size_t ka = AKM ? 1 : (size_t)lda, kb = BKM ? 1 : (size_t)ldb;
 
+    // k-major A with a row limit: a DMA instruction fills 8 whole tile rows, and the instructions whose rows
+    // all lie past the limit are not issued (their LDS rows feed only output rows that are never stored)
+    constexpr bool SKIP_A = IL && AKM;
+    const int a_live = SKIP_A ? max(0, min(NIA, (mlim - m0 - wave * NIA * 8 + 7) / 8)) : NIA;
     auto issue = [&](int t) {
         char* st = lds + (t % NS) * STAGE;
         const int k0 = kbeg + t * GEMM_BK;
-        dma_issue<BM, AKM, NW>(sa, k0 * ka, st, wave);
+        if (SKIP_A) {
+            typedef __attribute__((address_space(1))) const void* gptr_t;
+            typedef __attribute__((address_space(3))) void* lptr_t;
+#pragma unroll
+            for (int i = 0; i < NIA; ++i)
+                if (i < a_live)
+                    __builtin_amdgcn_global_load_lds((gptr_t)(sa[i] + k0 * ka), (lptr_t)(st + (wave * NIA + i) * 1024), 16, 0, 0);
+        } else {
+            dma_issue<BM, AKM, NW>(sa, k0 * ka, st, wave);
+        }
         dma_issue<BN, BKM, NW>(sb, k0 * kb, st + TA::BYTES, wave);
+    };
+    // wait until only the youngest tile's DMA instructions of this wave are in flight, then barrier
+    auto wait_keep_one_tile = [&]() {
+        if (!SKIP_A || a_live == NIA) { VMCNT_BARRIER(6); }
+        else if (a_live == 3) { VMCNT_BARRIER(5); }
+        else if (a_live == 2) { VMCNT_BARRIER(4); }
+        else if (a_live == 1) { VMCNT_BARRIER(3); }
+        else { VMCNT_BARRIER(2); }
     };
     auto compute = [&](const char* la) {
         const char* lb = la + TA::BYTES;
@@ -485,7 +506,7 @@ k_gemm_bf16_w8(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__
         if (nfull > 1) issue(1);
         for (int it = 0; it < nfull; ++it) {
             // tile `it` must have landed; the 6 DMA instructions of tile it+1 stay in flight
-            if (it + 1 < nfull) VMCNT_BARRIER(6); else VMCNT_BARRIER(0);
+            if (it + 1 < nfull) wait_keep_one_tile(); else VMCNT_BARRIER(0);
             if (it + 2 < nfull) issue(it + 2);
             compute(lds + (it % NS) * STAGE);
         }

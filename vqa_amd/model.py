@@ -178,6 +178,8 @@ class _VQAHeadModel(nn.Module):
         self._ctx = None
         self.grad_ready_hook = None   # callable(bucket_index) fired as gradient buckets complete
         self.kernel_events = None     # set to {} to collect per-kernel HIP event pairs
+        self.kernel_event_stride = 1  # time every n-th launch only (an event pair costs the stream ~10 us of gaps)
+        self._event_calls: Dict[str, int] = {}
         self._pending = None          # last gradient bucket of the previous train_step still in flight
         self._bptt = False            # the running forward keeps the encoder state for backward through time
         self._loss_pending = False    # the mean of the per-row losses is still to be reduced (by backward)
@@ -399,6 +401,10 @@ class _VQAHeadModel(nn.Module):
         """When kernel timing is switched on (self.kernel_events = {}), a (start, end) pair of HIP
         events on the launch stream around one kernel; the start event is recorded here."""
         if self.kernel_events is None:
+            return None
+        n = self._event_calls.get(name, 0)
+        self._event_calls[name] = n + 1
+        if n % self.kernel_event_stride:
             return None
         pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         self.kernel_events.setdefault(name, []).append(pair)
