@@ -81,3 +81,24 @@ def test_fp32_gemm():
         torch.cuda.synchronize()
         err = float((slab.double().sum(0) - ref).abs().max() / ref.abs().max())
         assert err <= 1e-6
+
+
+@pytest.mark.parametrize('engine', [4, 3, 2, 0])
+@pytest.mark.parametrize('akm,bkm', [(1, 1), (0, 1)])
+def test_device_side_row_limit(engine, akm, bkm):
+    """A device-side live-row count (sequences sorted by length: step t has m_t live rows).  Rows below the
+    limit are exact for every limit; the 256 x 128 engine leaves the rows past it untouched."""
+    M, N, K, sk = 700, 392, 2400, 3
+    As, lda, Bs, ldb, ref = make(M, N, K, akm, bkm, torch.bfloat16, 3)
+    for live in (1, 16, 17, 63, 64, 65, 127, 128, 129, 200, 255, 256, 257, 320, 333, 512, 699, 700, 900):
+        lim = torch.tensor([live], device='cuda', dtype=torch.int32)
+        slab = torch.full((sk, M, N), float('nan'), device='cuda')
+        call('vqa_gemm_slabs_rows', ptr(As), lda, akm, ptr(Bs), ldb, bkm, ptr(slab), M * N, N, M, N, K, sk, BF16, engine,
+             ptr(lim), None)
+        torch.cuda.synchronize()
+        n = min(live, M)
+        got = slab[:, :n].double().sum(0)
+        err = float((got - ref[:n]).abs().max() / ref.abs().max())
+        assert err <= 2e-5, (engine, akm, bkm, live, err)
+        if engine == 4 and akm and bkm and n < M:
+            assert bool(torch.isnan(slab[:, n:]).all()), (live, 'rows past the limit were written')
