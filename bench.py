@@ -78,6 +78,8 @@ def main():
     ap.add_argument('--regions', type=int, default=196)
     ap.add_argument('--hops', type=int, default=1)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--rccl-single', action='store_true',
+                    help='N=1 only: run the bucketed all-reduce path over a one-rank RCCL group (its cost without peers)')
     ap.add_argument('--event-stride', type=int, default=4,
                     help='HIP-event pairs go around every n-th launch of the roofline kernel inside the timed region')
     args = ap.parse_args()
@@ -89,6 +91,8 @@ def main():
     dev = torch.device('cuda', local)
     if world > 1:
         dist.init_process_group('nccl', device_id=dev)
+    elif args.rccl_single:
+        dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29533', rank=0, world_size=1, device_id=dev)
 
     from vqa_amd.model import VQAAttnModel
     from vqa_amd.parallel import GradReducer
@@ -96,7 +100,7 @@ def main():
     B, R, Dv, L, Vq, C = args.batch, args.regions, 2048, 14, 10000, 3000
     model = VQAAttnModel(['w'] * Vq, ['a'] * C, None, dtype=torch.bfloat16, hops=args.hops, seed=0).to(dev)
     model.train()
-    reducer = GradReducer() if world > 1 else None
+    reducer = GradReducer(force=args.rccl_single) if (world > 1 or args.rccl_single) else None
     nb = max(2, min(4, (320 << 20) // (B * R * Dv * 2) + 1))      # > 256 MiB of features in rotation
     batches = synth_batches(nb, B, R, Dv, L, Vq, C, dev, 42 + rank, torch.bfloat16)
 
@@ -157,7 +161,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(B, R, Dv, L, Vq, C, threads=min(16, os.cpu_count() or 1))
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or args.rccl_single:
         dist.destroy_process_group()
 
 

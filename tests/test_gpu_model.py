@@ -276,14 +276,20 @@ class _LoopbackReducer:
     identity, so parameters must come out bit-identical to the reducer-less step."""
     enabled, defer_last, world = True, True, 1
 
-    def __init__(self):
-        self.fired, self.last_waited = [], 0
+    def __init__(self, defer_all=False):
+        self.fired, self.last_waited, self.defer_all = [], 0, defer_all
+
+    def defer_everything(self):
+        self.deferred = True
+        self.fired = list(range(self.nb))
+        return 1.0
 
     def begin(self, model):
-        self.fired = []
+        self.fired, self.nb = [], len(model.buckets)
 
     def bucket_ready(self, index):
-        self.fired.append(index)
+        if index not in self.fired:
+            self.fired.append(index)
 
     def finish(self, defer_last=False):
         self.deferred = defer_last
@@ -293,15 +299,16 @@ class _LoopbackReducer:
         self.last_waited += 1
 
 
+@pytest.mark.parametrize('defer_all', [False, True])
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
-def test_deferred_last_bucket_is_exact(dtype):
+def test_deferred_last_bucket_is_exact(dtype, defer_all):
     """The last gradient bucket's Adam update is applied inside the next step (or by sync /
     state_dict); every parameter ends bit-identical to the undeferred schedule."""
     kw = MID
     ma, _ = build(kw, 2, False, dtype)
     mb, _ = build(kw, 2, False, dtype)
     ma.train(), mb.train()
-    red = _LoopbackReducer()
+    red = _LoopbackReducer(defer_all)
     lo, hi = None, None
     for step in range(1, 4):
         b = batch(kw, 16, 25, 14, seed=200 + step)
@@ -310,6 +317,8 @@ def test_deferred_last_bucket_is_exact(dtype):
         lb = mb.train_step(*args, lr=1e-3, reducer=red)
         assert torch.equal(la, lb)
         lo, hi = mb.buckets[-1]
+        if defer_all:                # every bucket's update is one step behind
+            lo = 0
         assert red.deferred and red.fired == list(range(len(mb.buckets)))
         assert mb._pending is not None and red.last_waited == step - 1
         torch.cuda.synchronize()    # the deferred slice is one update behind, the rest is current

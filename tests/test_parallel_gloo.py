@@ -51,10 +51,21 @@ def _worker(rank, world, port, out_dir):
     for i in range(len(fm2.buckets)):
         red.bucket_ready(i)
     assert red.finish(defer_last=True) == scale
-    assert len(red._handles) == 1
+    assert red._handles == [] and red._last_handle is not None
     red.finish_last()
-    assert red._handles == []
+    assert red._last_handle is None
     assert torch.equal(fm2._flat_grad, fm._flat_grad)
+    # the small buckets of this toy model were held back and reduced in one collective; the last went alone
+    assert red.launched == [(fm2.buckets[0][0], fm2.buckets[-2][1]), fm2.buckets[-1]]
+    # a byte threshold of zero reduces every bucket on its own; signalling out of order changes nothing
+    fm3 = _FakeModel(g, order, cuts=[4, 8, len(order) - 1])
+    red0 = GradReducer(bucket_bytes=0)
+    red0.begin(fm3)
+    for i in (2, 0, 3, 1):
+        red0.bucket_ready(i)
+    red0.finish()
+    assert red0.launched == list(fm3.buckets)
+    assert torch.equal(fm3._flat_grad, fm._flat_grad)
     # accuracy counters: integer sums
     logits = vqa_ref.forward(p, full['feats'][sl], full['tokens'][sl])
     pred = vqa_ref.argmax_first(logits.numpy())

@@ -729,8 +729,9 @@ class _VQAHeadModel(nn.Module):
         """forward + loss + backward (+ gradient all-reduce through `reducer`) + Adam
         (train.py:200-204 in one call).  Returns the loss as a 1-element device tensor.
         With a reducer whose `defer_last` is set, the all-reduce and Adam update of the last
-        gradient bucket are completed inside the next call (after its question-encoder / inv-norm
-        prologue, which they do not affect) or by sync(); results are identical either way."""
+        gradient bucket (of every bucket with `defer_all`) are completed inside the next call (after its
+        question-encoder / inv-norm prologue, which they do not affect) or by sync(); results are
+        identical either way."""
         feats, tokens, captions = self._prepare_inputs(input_v, input_q, captions)
         self._materialize(tokens.device)
         betas, eps = (0.9, 0.999), 1e-8
@@ -745,7 +746,13 @@ class _VQAHeadModel(nn.Module):
                 self._backward_impl()
             finally:
                 self.grad_ready_hook = None
-            if reducer is not None and reducer.enabled and reducer.defer_last and len(self.buckets) > 1:
+            if reducer is not None and reducer.enabled and getattr(reducer, 'defer_all', False):
+                scale = reducer.defer_everything()       # nothing is waited for inside the step
+                self.step_count += 1
+                self._pending = (reducer, 0, self._flat.numel(), lr, betas, eps, self.step_count, scale)
+                self._shadow_fresh = self.dt == _lib.BF16
+                self._shadow_version = self._flat._version
+            elif reducer is not None and reducer.enabled and reducer.defer_last and len(self.buckets) > 1:
                 scale = reducer.finish(defer_last=True)
                 lo, hi = self.buckets[-1]
                 self.step_count += 1

@@ -21,17 +21,34 @@ import torch.distributed as dist
 
 
 class GradReducer:
-    def __init__(self, process_group: Optional["dist.ProcessGroup"] = None, defer_last: bool = True):
+    def __init__(self, process_group: Optional["dist.ProcessGroup"] = None, defer_last: bool = True,
+                 force: bool = False, bucket_bytes: int = 32 << 20, defer_all: bool = True):
+        """`bucket_bytes`: completed buckets are held back until this much gradient is ready and then reduced
+        in one collective (every collective costs the compute stream two cross-stream dependencies, about
+        20 us of GPU time on MI355X, whatever its size); the last bucket always goes on its own so that it
+        can be deferred.  `force` issues the collectives even in a group of one rank (where they are the
+        identity): a single-GPU machine can then exercise the RCCL stream ordering of the bucketed path."""
         self.group = process_group
         # the last bucket (the image projection) only completes at the very end of backward: its
         # all-reduce is left running under the next step's parameter-independent prologue
         self.defer_last = defer_last
-        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1
+        # ... and with `defer_all` no bucket is waited for inside the step at all: every collective keeps
+        # running under the rest of backward and the next step's prologue, and the whole Adam update is
+        # applied there after a single cross-stream wait (same arithmetic, same results)
+        self.defer_all = defer_all and defer_last
+        self.bucket_bytes = bucket_bytes
+        self.enabled = dist.is_available() and dist.is_initialized() and (
+            dist.get_world_size(process_group) > 1 or force)
         self.world = dist.get_world_size(process_group) if self.enabled else 1
+        self._in_order = self.enabled and dist.get_backend(process_group) == 'nccl'
         self._handles: List = []
+        self._last_handle = None
         self._flat_grad: Optional[torch.Tensor] = None
         self._buckets: Sequence[Tuple[int, int]] = ()
         self._fired: List[bool] = []
+        self._next = 0                      # first bucket not yet handed to a collective or to the pending run
+        self._run: Optional[Tuple[int, int]] = None   # element range of the completed buckets being held back
+        self.launched: List[Tuple[int, int]] = []     # element ranges of the collectives of this pass, in order
 
     def begin(self, model) -> None:
         """Bind to the model's flat gradient buffer for one backward pass."""
@@ -39,17 +56,37 @@ class GradReducer:
         self._buckets = model.buckets
         self._fired = [False] * len(self._buckets)
         self._handles = []
+        self._last_handle = None
+        self._next, self._run = 0, None
+        self.launched = []
+
+    def _launch(self, s: int, e: int):
+        self.launched.append((s, e))
+        return dist.all_reduce(self._flat_grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def bucket_ready(self, index: int) -> None:
-        """Gradient bucket `index` is complete: start its all-reduce."""
+        """Gradient bucket `index` is complete.  Buckets are reduced in index order (the order backward
+        completes them); a bucket signalled early waits for its predecessors."""
         if self._fired[index]:
             return
         self._fired[index] = True
         if not self.enabled:
             return
-        s, e = self._buckets[index]
-        self._handles.append(dist.all_reduce(self._flat_grad[s:e], op=dist.ReduceOp.SUM, group=self.group,
-                                             async_op=True))
+        n = len(self._buckets)
+        while self._next < n and self._fired[self._next]:
+            i = self._next
+            self._next += 1
+            s, e = self._buckets[i]
+            if i == n - 1 and n > 1:        # the last bucket: on its own, after whatever was held back
+                if self._run is not None:
+                    self._handles.append(self._launch(*self._run))
+                    self._run = None
+                self._last_handle = self._launch(s, e)
+                continue
+            self._run = (self._run[0], e) if self._run is not None else (s, e)
+            if 4 * (self._run[1] - self._run[0]) >= self.bucket_bytes or i >= n - 2:
+                self._handles.append(self._launch(*self._run))
+                self._run = None
 
     def finish(self, defer_last: bool = False) -> float:
         """Wait for every bucket (reducing any that was never signalled) -- all but the last one
@@ -58,19 +95,35 @@ class GradReducer:
         for i, done in enumerate(self._fired):
             if not done:
                 self.bucket_ready(i)
-        keep = []
-        if defer_last and self.enabled and len(self._handles) == len(self._buckets):
-            keep = [self._handles.pop()]           # handles are in bucket order
-        for h in self._handles:
-            h.wait()
-        self._handles = keep
+        self._wait(self._handles)
+        self._handles = []
+        if not (defer_last and self.enabled):
+            self.finish_last()
         return 1.0 / self.world
 
+    def defer_everything(self) -> float:
+        """Start the collectives of any bucket not yet signalled and wait for none of them;
+        finish_last() completes them all.  Returns the same factor as finish()."""
+        for i, done in enumerate(self._fired):
+            if not done:
+                self.bucket_ready(i)
+        return 1.0 / self.world
+
+    def _wait(self, handles) -> None:
+        # RCCL runs a group's collectives in order on one stream: making the compute stream wait for the
+        # youngest one covers the older ones, and each wait that is saved is one cross-stream dependency
+        # less on the GPU.  Other backends complete their work items independently.
+        if handles and self._in_order:
+            handles[-1].wait()
+        else:
+            for h in handles:
+                h.wait()
+
     def finish_last(self) -> None:
-        """Wait for the bucket left in flight by finish(defer_last=True)."""
-        for h in self._handles:
-            h.wait()
-        self._handles = []
+        """Wait for whatever finish(defer_last=True) or defer_everything() left in flight."""
+        pending = self._handles + ([self._last_handle] if self._last_handle is not None else [])
+        self._wait(pending)
+        self._handles, self._last_handle = [], None
 
 
 def reduce_counters(counters: torch.Tensor, process_group=None) -> torch.Tensor:
