@@ -29,3 +29,12 @@ if __name__ == '__main__':
         run('K4 fwd NT', 50176, 1200, 2048, True, True, [(6, 1), (8, 1), (9, 1)])
         run('square', 8192, 8192, 8192, True, True, [(6, 1), (8, 1), (9, 1)])
         run('wgrad TN', 1200, 2048, 50176, False, False, [(6, 6), (8, 6), (9, 6)])
+    # the small products of the head (batch 256)
+    for _ in range(2):
+        run('classif2 fwd', 256, 3000, 256, True, True, [(2, 1), (3, 1)])
+        run('classif2 wgr', 3000, 256, 256, False, False, [(2, 1), (3, 1)])
+        run('classif2 dgr', 256, 256, 3000, True, False, [(2, 4), (3, 4), (2, 8)])
+        run('lin_v wgrad', 1200, 2048, 256, False, False, [(2, 1), (3, 1), (4, 1)])
+        run('lin_q wgrad', 1200, 2400, 256, False, False, [(2, 1), (3, 1), (4, 1)])
+        run('qa fwd', 256, 1200, 2400, True, True, [(2, 6), (2, 4), (2, 3), (3, 6), (3, 9)])
+        run('lin_v dgrad', 256, 2048, 1200, True, False, [(2, 4), (2, 2), (3, 4), (3, 8)])

@@ -740,6 +740,9 @@ static inline int pick_tile(int M, int N, int K, int akm, int bkm, int engine) {
     // before its MFMAs (engine 9) is the faster one: 6-8 % at 8192^3, 2 % on the image projection inside the step
     if (M >= 384 && N >= 192 && t512 >= 32 && t512 * split512 >= 192 && !ragged) return (akm && bkm) ? 4096 : 512;
     if (akm && bkm && M >= 192 && N > 64 && t256 >= 40) return 256;   // 256 x 128 tiles, 3-stage ring
+    // a short contraction (a handful of K steps) is all ramp-up: more, smaller workgroups start and finish
+    // sooner unless the 128 x 128 tiles already give every CU one
+    if (K <= 512 && t128 < 256) return 64;
     return (M > 64 && N > 64 && t128 >= 40) ? 128 : 64;
 }
 

@@ -365,8 +365,12 @@ class _VQAHeadModel(nn.Module):
     def _wgrad(self, dy, ld_dy, x, ldx, wname, M, N, K, active_k=None, defer=False):
         """grad(W)[M,N] = dy^T x with dy stored [K][M], x stored [K][N].  defer: the split-K partial sums go to
         an arena of their own and are reduced later, together with the other deferred ones, by _flush_wgrads()."""
+        sk = call('vqa_gemm_splitk_hint', M, N, K, 0, 0)
+        if sk == 1:                 # a single K range: the product is the gradient, written in place
+            call('vqa_gemm_slabs_rows', ptr(dy), ld_dy, 0, ptr(x), ldx, 0, ptr(self._g(wname)), M * N, N, M, N, K, 1,
+                 self.dt, self.gemm_engine, None, active_k)
+            return
         if defer:
-            sk = call('vqa_gemm_splitk_hint', M, N, K, 0, 0)
             stride = M * N
             addr = self._arena(sk * stride, dy.device)
             call('vqa_gemm_slabs_rows', ptr(dy), ld_dy, 0, ptr(x), ldx, 0, addr, stride, N, M, N, K, sk,
