@@ -196,6 +196,16 @@ int vqa_gemm_fused(const void* A, int lda, int a_kmajor, const void* B, int ldb,
                    int M, int N, int K, const float* bias, const float* row_scale, int act, int out_dtype,
                    int dtype, int engine, hipStream_t stream);
 
+/* C = act(inv_norm[m] * (A B^T) + bias[n]) with inv_norm[m] = 1 / max(||A[m,:]||_2, 1e-12) computed by the
+ * same launch and also stored to inv_norm (M floats): F.normalize(v, dim=-1) folded into the projection that
+ * consumes it.  A [M][K] and B [N][K] are k-major.  With bf16 operands and a product large enough for the
+ * 256 x 256 ring kernel the row norms come from the A tiles already in LDS (A is read once); otherwise the
+ * call runs vqa_inv_norm followed by vqa_gemm_fused.  No reference counterpart (the reference has no
+ * normalised projection: model.py:161-164 pools with a mean). */
+int vqa_gemm_fused_rownorm(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
+                           const float* bias, float* inv_norm, int act, int out_dtype, int dtype, int engine,
+                           hipStream_t stream);
+
 /* ---- split-K reduce + epilogues of the head ------------------------------------ */
 
 /* v = act(row_scale[m] * sum_s slabs[s][m][n] + bias[n] + addend[m][n]), act 0 none, 1 tanh, 2 sigmoid;

@@ -102,3 +102,33 @@ def test_device_side_row_limit(engine, akm, bkm):
         assert err <= 2e-5, (engine, akm, bkm, live, err)
         if engine == 4 and akm and bkm and n < M:
             assert bool(torch.isnan(slab[:, n:]).all()), (live, 'rows past the limit were written')
+
+
+@pytest.mark.parametrize('M,N,K', [(12547, 1200, 2072), (300, 136, 256), (4099, 520, 64), (50176, 1200, 2048)])
+@pytest.mark.parametrize('out_dtype', [torch.bfloat16, torch.float32])
+def test_projection_with_fused_row_norm(M, N, K, out_dtype):
+    """C = normalize(A) B^T + bias in one call (ring kernel: norms from the A tiles in LDS; small products: norm
+    kernel + product), and the inverse norms it stores, against fp64 from the same bf16 operands."""
+    As, lda, Bs, ldb, ref = make(M, N, K, 1, 1, torch.bfloat16, M % 97)
+    As[5].zero_()                                            # an all-zero row: scale 1e12 times 0
+    ref[5].zero_()
+    g = torch.Generator(device='cuda').manual_seed(9)
+    bias = torch.randn(N, device='cuda', generator=g)
+    ldc = (N + 7) // 8 * 8
+    C = torch.zeros(M, ldc, device='cuda', dtype=out_dtype)
+    inv = torch.full((M,), float('nan'), device='cuda')
+    call('vqa_gemm_fused_rownorm', ptr(As), lda, ptr(Bs), ldb, ptr(C), ldc, M, N, K, ptr(bias), ptr(inv), 0,
+         BF16 if out_dtype == torch.bfloat16 else F32, BF16, 0)
+    torch.cuda.synchronize()
+    norm = As[:, :K].double().norm(dim=1)
+    inv_ref = 1.0 / norm.clamp_min(1e-12)
+    assert float(((inv.double() - inv_ref).abs() / inv_ref).max()) <= 1e-5
+    want = ref * inv_ref[:, None] + bias.double()[None, :]
+    tol = 1e-2 if out_dtype == torch.bfloat16 else 3e-5
+    err = float((C[:, :N].double() - want).abs().max() / want.abs().max())
+    assert err <= tol, (M, N, K, err)
+    # the separate norm kernel gives the same scales to fp32 rounding
+    inv2 = torch.empty_like(inv)
+    call('vqa_inv_norm', ptr(As), ptr(inv2), M, K, lda, BF16)
+    torch.cuda.synchronize()
+    assert float(((inv - inv2).abs() / inv2).max()) <= 1e-5

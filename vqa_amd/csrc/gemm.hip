@@ -33,6 +33,8 @@ struct Epi {
     const float* bias; const float* row_scale; int act;
     const int* m_limit;        // optional device-side row count: row tiles starting at or past *m_limit are not computed
     const int* k_limit;        // optional device-side contraction length: only k < *k_limit contributes
+    float* norm_out;           // ring kernel with NORM: the row scale is 1 / max(||A[m,:]||, 1e-12), computed from the
+                               // A tiles as they pass through and also stored here (by the workgroups of column tile 0)
     __device__ __forceinline__ int kcap(int K) const { return k_limit ? min(K, *k_limit) : K; }
     __device__ __forceinline__ float value(float v, float rs, float b) const {
         v = v * rs + b;
@@ -198,7 +200,8 @@ __device__ __forceinline__ bf16x8_t frag_read(const char* lds, int r0, int kk, i
 // FS = distance in rows between a wave's consecutive 16-row fragments (16: one contiguous band).
 template <int MT, int NT, int FS = 16>
 __device__ __forceinline__ void epilogue_store(char* lds, f32x4 (&acc)[MT][NT], const Epi& epi, int split,
-                                               int m_w, int n_w, int M, int N, int wave, int lane) {
+                                               int m_w, int n_w, int M, int N, int wave, int lane,
+                                               const float* rs_tile = nullptr, int m_tile0 = 0) {
     constexpr int WN = NT * 16, LDW = WN + 4;
     float* wl = reinterpret_cast<float*>(lds) + wave * (32 * LDW);
     float bias[NT];
@@ -218,7 +221,7 @@ __device__ __forceinline__ void epilogue_store(char* lds, f32x4 (&acc)[MT][NT], 
             for (int r = 0; r < 4; ++r) {
                 const int rl = ii * 16 + (lane >> 4) * 4 + r;
                 const int m = m_w + i * FS + (lane >> 4) * 4 + r;
-                const float rs = (epi.row_scale && m < M) ? epi.row_scale[m] : 1.f;
+                const float rs = rs_tile ? rs_tile[m - m_tile0] : ((epi.row_scale && m < M) ? epi.row_scale[m] : 1.f);
 #pragma unroll
                 for (int j = 0; j < NT; ++j) wl[rl * LDW + j * 16 + (lane & 15)] = epi.value(acc[i][j][r], rs, bias[j]);
             }
@@ -540,7 +543,10 @@ k_gemm_bf16_w8(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__
 // tile t + 2 are resident or in flight, and the four slots tile t - 1 occupied are refilled at once,
 // so the DMA queue never drains (a two-slot ring waits for every tile with an empty queue, which
 // costs about half the fetch rate).  One counted wait + raw barrier per K tile.
-template <bool AKM, bool BKM, int PF>
+// NORM (k-major A, one K split): each wave also accumulates the sums of squares of its 128 A rows from the
+// fragments it reads anyway (v_dot2 on bf16 pairs, 4 instructions per fragment), and the epilogue scales row m
+// by 1 / max(||A[m,:]||, 1e-12): the separate pass over A that a row normalisation would cost is saved.
+template <bool AKM, bool BKM, int PF, bool NORM = false>
 __global__ void __launch_bounds__(512)
 k_gemm_bf16_r10(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, int M, int N, int K,
                 int tiles_m, int tiles_n, int k_per_split, Epi epi) {
@@ -570,6 +576,9 @@ k_gemm_bf16_r10(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict_
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    static_assert(!NORM || (AKM && PF == 0), "row norms come from k-major A fragments of the one-sub-step schedule");
+    float ss[2] = {0.f, 0.f};          // NORM: this lane's share of the squares of rows (2 wn + e) * 16 + (lane & 15)
 
     // two DMA instructions per wave and quarter
     const bf16_t* sa0[2]; const bf16_t* sa1[2]; const bf16_t* sb0[2]; const bf16_t* sb1[2];
@@ -620,6 +629,18 @@ k_gemm_bf16_r10(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict_
                 for (int i = 0; i < MT; ++i) fa[i] = frag_read<128, AKM>(la, i * 16, kk, lane);
 #pragma unroll
                 for (int j = 0; j < NT; ++j) fb[j] = frag_read<128, BKM>(lb, bc + j * 16, kk, lane);
+                if (NORM) {
+                    // the four column-waves that share these 128 rows take two of the eight row fragments each
+                    // (read once more from LDS: a register array cannot be indexed by the wave id)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const bf16x8_t v = frag_read<128, AKM>(la, (2 * wn + e) * 16, kk, lane);
+                        ss[e] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(v, v, 0, 1), __builtin_shufflevector(v, v, 0, 1), ss[e], false);
+                        ss[e] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(v, v, 2, 3), __builtin_shufflevector(v, v, 2, 3), ss[e], false);
+                        ss[e] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(v, v, 4, 5), __builtin_shufflevector(v, v, 4, 5), ss[e], false);
+                        ss[e] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(v, v, 6, 7), __builtin_shufflevector(v, v, 6, 7), ss[e], false);
+                    }
+                }
                 __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
@@ -659,6 +680,25 @@ k_gemm_bf16_r10(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict_
         compute(lds + wm * QB, lds + (2 + (wn >> 1)) * QB);
     }
     VMCNT_BARRIER(0);
+    if (NORM) {
+        // a lane holds the squares of 8 of its row's 32 k's per sub-step: the four 16-lane groups add up to the row
+        float* rs_tile = reinterpret_cast<float*>(lds + EPI_BYTES);          // 256 row scales, past the store staging area
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            float v = ss[e];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            const float inv = 1.0f / fmaxf(sqrtf(v), 1e-12f);
+            const int row = wm * 128 + (2 * wn + e) * 16 + (lane & 15);
+            if (lane < 16) {
+                rs_tile[row] = inv;
+                if (n0 == 0 && m0 + row < M) epi.norm_out[m0 + row] = inv;
+            }
+        }
+        __syncthreads();
+        epilogue_store<MT, NT>(lds, acc, epi, split, m0 + wm * 128, n0 + wn * 64, M, N, wave, lane, rs_tile, m0);
+        return;
+    }
     epilogue_store<MT, NT>(lds, acc, epi, split, m0 + wm * 128, n0 + wn * 64, M, N, wave, lane);
 }
 
@@ -873,6 +913,26 @@ int vqa_gemm_fused_rows(const void* A, int lda, int a_kmajor, const void* B, int
     else if (dtype == VQA_BF16) launch_valu<bf16_t>(A, lda, a_kmajor, B, ldb, b_kmajor, M, N, K, 1, epi, stream);
     else launch_valu<float>(A, lda, a_kmajor, B, ldb, b_kmajor, M, N, K, 1, epi, stream);
     return vqa_check_launch("vqa_gemm_fused");
+}
+
+int vqa_gemm_fused_rownorm(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
+                           const float* bias, float* inv_norm, int act, int out_dtype, int dtype, int engine,
+                           hipStream_t stream) {
+    if (int rc = gemm_check(A, lda, 1, B, ldb, 1, M, N, K, dtype, engine)) return rc;
+    VQA_REQUIRE(C && ldc >= N && inv_norm, "vqa_gemm_fused_rownorm: bad output");
+    VQA_REQUIRE(act == 0 || act == 1, "vqa_gemm_fused_rownorm: act must be 0 (none) or 1 (tanh)");
+    VQA_REQUIRE(out_dtype == VQA_F32 || out_dtype == VQA_BF16, "vqa_gemm_fused_rownorm: out_dtype");
+    const int bm = (dtype == VQA_BF16 && engine != 1) ? pick_tile(M, N, K, 1, 1, engine) : 0;
+    if (bm == 2048 || bm == 4096) {
+        Epi epi{C, ldc, out_dtype == VQA_BF16, 0, bias, nullptr, act, nullptr, nullptr, inv_norm};
+        const int tm = ceil_div(M, 256), tn = ceil_div(N, 256);
+        const int kps = ceil_div(K, GEMM_BK) * GEMM_BK;
+        k_gemm_bf16_r10<true, true, 0, true><<<(unsigned)(tm * tn), 512, 0, stream>>>(
+            (const bf16_t*)A, lda, (const bf16_t*)B, ldb, M, N, K, tm, tn, kps, epi);
+        return vqa_check_launch("vqa_gemm_fused_rownorm");
+    }
+    if (int rc = vqa_inv_norm(A, inv_norm, M, K, lda, dtype, stream)) return rc;
+    return vqa_gemm_fused(A, lda, 1, B, ldb, 1, C, ldc, M, N, K, bias, inv_norm, act, out_dtype, dtype, engine, stream);
 }
 
 int vqa_gemm_fused(const void* A, int lda, int a_kmajor, const void* B, int ldb, int b_kmajor, void* C, int ldc,

@@ -873,9 +873,12 @@ class VQAAttnModel(_VQAHeadModel):
                 ws[f'u32_{k}'] = z((B, H), f32)
                 ws[f'uT_{k}'] = z((B, H), tdt)
 
+    fuse_row_norm = True     # the first hop's projection computes the region norms itself (one pass over the features less)
+
     def _visual_prologue(self, ws, feats, B):
         R, Dv = feats.shape[1], self.Dv
-        call('vqa_inv_norm', ptr(feats), ptr(ws['inv_norm']), B * R, Dv, Dv, self.dt)
+        if not self.fuse_row_norm:
+            call('vqa_inv_norm', ptr(feats), ptr(ws['inv_norm']), B * R, Dv, Dv, self.dt)
 
     def _visual_forward(self, ws, feats, B, seed, p):
         R = feats.shape[1]
@@ -883,8 +886,12 @@ class VQAAttnModel(_VQAHeadModel):
         u32, uT = ws['q32'], ws['qT']
         for k in range(self.hops):
             pre = f'attention.{k}.'
-            call('vqa_gemm_fused', ptr(feats), Dv, 1, ptr(self._w(pre + 'linear_va.weight')), Dv, 1, ptr(ws[f'P{k}']), A,
-                 B * R, A, Dv, ptr(self._f32(pre + 'linear_va.bias')), ptr(ws['inv_norm']), 0, dt, dt, self.gemm_engine)
+            if k == 0 and self.fuse_row_norm:       # P = normalize(V) W_va^T + b, inv_norm written by the same launch
+                call('vqa_gemm_fused_rownorm', ptr(feats), Dv, ptr(self._w(pre + 'linear_va.weight')), Dv, ptr(ws[f'P{k}']), A,
+                     B * R, A, Dv, ptr(self._f32(pre + 'linear_va.bias')), ptr(ws['inv_norm']), 0, dt, dt, self.gemm_engine)
+            else:
+                call('vqa_gemm_fused', ptr(feats), Dv, 1, ptr(self._w(pre + 'linear_va.weight')), Dv, 1, ptr(ws[f'P{k}']), A,
+                     B * R, A, Dv, ptr(self._f32(pre + 'linear_va.bias')), ptr(ws['inv_norm']), 0, dt, dt, self.gemm_engine)
             self._linear(uT, H, pre + 'linear_qa.weight', pre + 'linear_qa.bias', B, A, H, out_pre=ws[f'qa{k}'], ld_pre=A)
             ev = self._event_pair('attn_fwd')
             call('vqa_attn_fwd', ptr(ws[f'P{k}']), A, ptr(feats), Dv, ptr(ws[f'qa{k}']), A,
