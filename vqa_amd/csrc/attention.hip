@@ -684,6 +684,14 @@ k_attn_bwd_pipe(const bf16_t* __restrict__ P, int ldP, const bf16_t* __restrict_
     }
     __syncthreads();
 
+    // phase C's geometry, and its first batch of P rows requested now: they do not depend on phase B
+    const int G = ATT_THREADS / nva, grp = tid / nva, cv = tid % nva;
+    const bool active = grp < G;
+    const bf16_t* colP = Pb + (active ? cv : 0) * 8;
+    u32x4_t xc[4], xn[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) xc[u] = __builtin_bit_cast(u32x4_t, ld_stream(colP + (size_t)min(min(grp, G - 1) + u * G, R - 1) * ldP));
+
     // ---- phase B: softmax backward -----------------------------------------------------
     float dot = 0.f;
     for (int r = tid; r < R; r += ATT_THREADS) dot += p_in[(size_t)b * R + r] * ds_s[r];
@@ -699,8 +707,6 @@ k_attn_bwd_pipe(const bf16_t* __restrict__ P, int ldP, const bf16_t* __restrict_
     __syncthreads();
 
     // ---- phase C: stream P, write dP, accumulate dqa / dwa; 4 rows in flight per thread ------
-    const int G = ATT_THREADS / nva, grp = tid / nva, cv = tid % nva;
-    const bool active = grp < G;
     const float kk = 2.8853900817779268f;
     float aq[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ar[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     float dssum = 0.f;
@@ -713,7 +719,6 @@ k_attn_bwd_pipe(const bf16_t* __restrict__ P, int ldP, const bf16_t* __restrict_
 #pragma unroll
             for (int e = 0; e < 4; ++e) { qk[e] = q0[e] * kk; qk[4 + e] = q1[e] * kk; w4[e] = 4.f * g0[e]; w4[4 + e] = 4.f * g1[e]; }
         }
-        const bf16_t* colP = Pb + cv * 8;
         bf16_t* colD = dPb + cv * 8;
         auto body = [&](const u32x4_t& x, int r) {
             const float ds = ds_s[r], wn = wn_s[r];
@@ -739,9 +744,6 @@ k_attn_bwd_pipe(const bf16_t* __restrict__ P, int ldP, const bf16_t* __restrict_
         };
         // two batches of 4 rows in flight: the next batch is requested before the current one is consumed
         // (row indices clamped, so every load is unconditional; rows past R are not consumed)
-        u32x4_t xc[4], xn[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) xc[u] = __builtin_bit_cast(u32x4_t, ld_stream(colP + (size_t)min(grp + u * G, R - 1) * ldP));
         for (int r = grp; r < R; r += 4 * G) {
             if (r + 4 * G < R) {
 #pragma unroll
