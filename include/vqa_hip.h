@@ -221,6 +221,12 @@ int vqa_dropout(const void* x, int ldx, void* y, int ldy, int M, int N, unsigned
 /* x = dropout(tanh(xv * xq))                                              model.py:71-73 */
 int vqa_fusion_fwd(const float* xv, const float* xq, void* x, int ldx, int B, int F, unsigned seed, float p,
                    int dtype, hipStream_t stream);
+/* The same fused into the reduction of linear_q's split-K partial sums: xq = tanh(sum_s slabs + bias) is stored
+ * (B, F) fp32 and x = dropout(tanh(xv * xq)); one launch instead of vqa_epilogue + vqa_fusion_fwd, same values
+ * and the same dropout mask.                                                  model.py:68-73 */
+int vqa_epilogue_fusion(const float* slabs, int nslab, size_t slab_stride, int B, int F, const float* bias,
+                        const float* xv, float* xq, void* x, int ldx, unsigned seed, float p, int dtype,
+                        hipStream_t stream);
 /* backward of the above down to the pre-activations of linear_v / linear_q (xv, xq are
  * the stored tanh outputs): dzv = dx drop (1-t^2) xq (1-xv^2), dzq likewise */
 int vqa_fusion_bwd(const float* slabs, int nslab, size_t slab_stride, int ldslab, const float* xv, const float* xq,

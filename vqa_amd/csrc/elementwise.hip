@@ -367,7 +367,7 @@ __global__ void k_epilogue(const float* __restrict__ slabs, int nslab, size_t sl
                            const float* __restrict__ bias, const float* __restrict__ row_scale,
                            const float* __restrict__ addend, int ld_add, int act, int accurate,
                            float* __restrict__ out_pre, int ld_pre, TP* __restrict__ out_post, int ld_post,
-                           unsigned seed, unsigned thr, float dscale) {
+                           unsigned seed, unsigned thr, float dscale, const float* __restrict__ mul = nullptr) {
     const long total = (long)M * N;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int m = (int)(i / N), n = (int)(i % N);
@@ -379,6 +379,10 @@ __global__ void k_epilogue(const float* __restrict__ slabs, int nslab, size_t sl
         if (act == 1) v = accurate ? tanhf(v) : fast_tanh(v);
         else if (act == 2) v = accurate ? 1.0f / (1.0f + expf(-v)) : fast_sigmoid(v);
         if (out_pre) out_pre[(size_t)m * ld_pre + n] = v;
+        if (mul) {                       // fusion head: out_post = dropout(tanh(v * mul[m][n])), mul stored (M, N)
+            const float w = v * mul[i];
+            v = accurate ? tanhf(w) : fast_tanh(w);
+        }
         if (out_post) out_post[(size_t)m * ld_post + n] = from_f32<TP>(v * drop_mult(seed, (unsigned)i, thr, dscale));
     }
 }
@@ -986,6 +990,25 @@ int vqa_fusion_fwd(const float* xv, const float* xq, void* x, int ldx, int B, in
     const float ds = 1.0f / (1.0f - p);
     DISPATCH_T(dtype, (k_fusion_fwd<T><<<grid_for((long)B * F, 256), 256, 0, stream>>>(xv, xq, (T*)x, ldx, B, F, seed, thr, ds)));
     return vqa_check_launch("vqa_fusion_fwd");
+}
+
+int vqa_epilogue_fusion(const float* slabs, int nslab, size_t slab_stride, int B, int F, const float* bias,
+                        const float* xv, float* xq, void* x, int ldx, unsigned seed, float p, int dtype,
+                        hipStream_t stream) {
+    VQA_REQUIRE(slabs && nslab >= 1 && xv && xq && x && B >= 0 && F > 0 && ldx >= F, "vqa_epilogue_fusion: bad arguments");
+    VQA_REQUIRE(p >= 0.f && p < 1.f, "vqa_epilogue_fusion: p must be in [0, 1)");
+    if (B == 0) return 0;
+    const unsigned thr = drop_threshold(p);
+    const float ds = 1.0f / (1.0f - p);
+    const int grid = grid_for((long)B * F, 256);
+    if (dtype == VQA_F32)
+        k_epilogue<float><<<grid, 256, 0, stream>>>(slabs, nslab, slab_stride, B, F, bias, nullptr, nullptr, 0, 1, 1, xq, F,
+                                                    (float*)x, ldx, seed, thr, ds, xv);
+    else if (dtype == VQA_BF16)
+        k_epilogue<bf16_t><<<grid, 256, 0, stream>>>(slabs, nslab, slab_stride, B, F, bias, nullptr, nullptr, 0, 1, 0, xq, F,
+                                                     (bf16_t*)x, ldx, seed, thr, ds, xv);
+    else return vqa_set_error(-22, "vqa_epilogue_fusion: dtype");
+    return vqa_check_launch("vqa_epilogue_fusion");
 }
 
 int vqa_fusion_bwd(const float* slabs, int nslab, size_t slab_stride, int ldslab, const float* xv, const float* xq,

@@ -558,8 +558,10 @@ class _VQAHeadModel(nn.Module):
         if self.seq2vec.arch == '2-lstm':       # (the single-layer encoder's cell kernel wrote q_d already)
             call('vqa_dropout', ptr(ws['qT']), H, ptr(ws['q_d']), H, B, H, seeds[1], p, dt)
         self._linear(ws['pooled_d'], Dv, 'linear_v.weight', 'linear_v.bias', B, F, Dv, act=1, out_pre=ws['xv'], ld_pre=F)
-        self._linear(ws['q_d'], H, 'linear_q.weight', 'linear_q.bias', B, F, H, act=1, out_pre=ws['xq'], ld_pre=F)
-        call('vqa_fusion_fwd', ptr(ws['xv']), ptr(ws['xq']), ptr(ws['x']), F + Ec, B, F, seeds[2], p, dt)
+        # xq = tanh(linear_q(q)) and the fusion x = dropout(tanh(xv * xq)) in the launch that reduces linear_q's slabs
+        slab, sk, st = self._gemm_slabs(ws['q_d'], H, 1, self._w('linear_q.weight'), H, 1, B, F, H)
+        call('vqa_epilogue_fusion', ptr(slab), sk, st, B, F, ptr(self._f32('linear_q.bias')), ptr(ws['xv']), ptr(ws['xq']),
+             ptr(ws['x']), F + Ec, seeds[2], p, dt)
         if Ec:
             call('vqa_caption_pool', ptr(captions), ptr(self._cap_t), ptr(ws['x']), B, Tc, Ec, Ec,
                  self._cap_t.shape[0], F + Ec, F, dt)
