@@ -79,6 +79,7 @@ def main():
     ap.add_argument('--hops', type=int, default=1)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-fuse-norm', action='store_true', help='A/B: separate row-norm pass before the image projection')
+    ap.add_argument('--no-swap-wgrad', action='store_true', help='A/B: dW_va in the nn.Linear orientation')
     ap.add_argument('--rccl-single', action='store_true',
                     help='N=1 only: run the bucketed all-reduce path over a one-rank RCCL group (its cost without peers)')
     ap.add_argument('--event-stride', type=int, default=4,
@@ -103,6 +104,8 @@ def main():
     model.train()
     if args.no_fuse_norm:
         model.fuse_row_norm = False
+    if args.no_swap_wgrad:
+        model.swap_big_wgrad = False
     reducer = GradReducer(force=args.rccl_single) if (world > 1 or args.rccl_single) else None
     nb = max(2, min(4, (320 << 20) // (B * R * Dv * 2) + 1))      # > 256 MiB of features in rotation
     batches = synth_batches(nb, B, R, Dv, L, Vq, C, dev, 42 + rank, torch.bfloat16)

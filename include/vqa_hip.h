@@ -243,6 +243,11 @@ int vqa_colsum(const void* X, int ld, float* out, int M, int N, int dtype, hipSt
 #define VQA_SLABSUM_MAX 8
 typedef struct VqaSlabSumDesc { const float* slabs; int nslab; size_t slab_stride; long count; float* out; } VqaSlabSumDesc;
 int vqa_slab_sum_multi(const VqaSlabSumDesc* descs, int n, hipStream_t stream);
+/* out[n][m] = sum_s slabs[s][m][n] (slabs of M x N floats, out rows of ld_out >= M floats): the reduction of a
+ * weight gradient whose product ran with the operand roles swapped -- dW^T = x^T dy is the faster orientation
+ * on MI355X when dy has the narrower, unaligned rows -- back into the nn.Linear layout.   autograd of model.py:55-58 */
+int vqa_slab_sum_transpose(const float* slabs, int nslab, size_t slab_stride, int M, int N, float* out, int ld_out,
+                           hipStream_t stream);
 /* up to VQA_COLSUM_MAX such sums in one launch (the bias gradients of a backward pass); out2 (optional)
  * receives the same sums (two biases added to the same pre-activation share their gradient); every sum is
  * multiplied by scale (1 for a gradient, 1/B for the mean of the per-row losses) */

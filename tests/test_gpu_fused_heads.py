@@ -26,3 +26,18 @@ def test_epilogue_fusion_matches_two_launches(dtype, B, F, pad, sk):
     assert torch.equal(xq_a, xq_b)
     assert torch.equal(x_a, x_b)
     assert 0.3 < float((x_b[:, :F] != 0).float().mean()) < 0.7
+
+
+@pytest.mark.parametrize('M,N,sk', [(2048, 1200, 6), (33, 65, 1), (1, 7, 3), (100, 31, 2)])
+def test_slab_sum_transpose(M, N, sk):
+    g = torch.Generator(device='cuda').manual_seed(M + N)
+    slabs = torch.randn(sk, M, N, device='cuda', generator=g)
+    ld = M + 8
+    out = torch.full((N, ld), 7.0, device='cuda')
+    call('vqa_slab_sum_transpose', ptr(slabs), sk, M * N, M, N, ptr(out), ld)
+    torch.cuda.synchronize()
+    ref = slabs[0].clone()
+    for s in range(1, sk):
+        ref += slabs[s]                       # the kernel's summation order
+    assert torch.equal(out[:, :M], ref.t())
+    assert bool((out[:, M:] == 7.0).all())

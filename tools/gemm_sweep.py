@@ -25,16 +25,19 @@ def run(name, M, N, K, akm, bkm, variants):
         print(f'{name:12s} M={M:6d} N={N:5d} K={K:6d} tile={ {2: "64", 3: "128", 4: "256x128", 6: "256x256", 8: "256x256r10", 9: "256x256r10pf"}[eng] } splitk={sk:2d}: {us:8.1f} us  {2.0 * M * N * K / us / 1e6:7.1f} TF')
 
 if __name__ == '__main__':
-    for _ in range(2):
-        run('K4 fwd NT', 50176, 1200, 2048, True, True, [(6, 1), (8, 1), (9, 1)])
-        run('square', 8192, 8192, 8192, True, True, [(6, 1), (8, 1), (9, 1)])
-        run('wgrad TN', 1200, 2048, 50176, False, False, [(6, 6), (8, 6), (9, 6)])
-    # the small products of the head (batch 256)
-    for _ in range(2):
-        run('classif2 fwd', 256, 3000, 256, True, True, [(2, 1), (3, 1)])
-        run('classif2 wgr', 3000, 256, 256, False, False, [(2, 1), (3, 1)])
-        run('classif2 dgr', 256, 256, 3000, True, False, [(2, 4), (3, 4), (2, 8)])
-        run('lin_v wgrad', 1200, 2048, 256, False, False, [(2, 1), (3, 1), (4, 1)])
-        run('lin_q wgrad', 1200, 2400, 256, False, False, [(2, 1), (3, 1), (4, 1)])
-        run('qa fwd', 256, 1200, 2400, True, True, [(2, 6), (2, 4), (2, 3), (3, 6), (3, 9)])
-        run('lin_v dgrad', 256, 2048, 1200, True, False, [(2, 4), (2, 2), (3, 4), (3, 8)])
+    which = sys.argv[1] if len(sys.argv) > 1 else 'big'
+    if which == 'big':
+        for _ in range(2):
+            run('K4 fwd NT', 50176, 1200, 2048, True, True, [(6, 1), (8, 1), (9, 1)])
+            run('square', 8192, 8192, 8192, True, True, [(6, 1), (8, 1), (9, 1)])
+            run('wgrad TN', 1200, 2048, 50176, False, False, [(6, 6), (8, 6), (9, 6), (4, 3), (6, 5), (6, 7)])
+            run('wgrad TN swapped', 2048, 1200, 50176, False, False, [(6, 6), (8, 6), (4, 3)])
+    else:
+        for _ in range(2):
+            run('classif2 fwd', 256, 3000, 256, True, True, [(2, 1), (3, 1)])
+            run('classif2 wgr', 3000, 256, 256, False, False, [(2, 1), (3, 1)])
+            run('classif2 dgr', 256, 256, 3000, True, False, [(2, 4), (3, 4), (2, 8)])
+            run('lin_v wgrad', 1200, 2048, 256, False, False, [(2, 1), (3, 1), (4, 1)])
+            run('lin_q wgrad', 1200, 2400, 256, False, False, [(2, 1), (3, 1), (4, 1)])
+            run('qa fwd', 256, 1200, 2400, True, True, [(2, 6), (2, 4), (2, 3), (3, 6), (3, 9)])
+            run('lin_v dgrad', 256, 2048, 1200, True, False, [(2, 4), (2, 2), (3, 4), (3, 8)])

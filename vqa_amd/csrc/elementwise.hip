@@ -499,6 +499,29 @@ __global__ void __launch_bounds__(256) k_slab_sum_multi(SlabSumBatch batch) {
     }
 }
 
+// out[n][m] = sum_s slabs[s][m][n]: split-K reduce of a product that was computed as its transpose.
+// 32 x 32 tiles through LDS: rows of the slabs are read and rows of `out` are written as 128-byte segments.
+__global__ void __launch_bounds__(256) k_slab_sum_transpose(const float* __restrict__ slabs, int nslab, size_t slab_stride,
+                                                            int M, int N, float* __restrict__ out, int ld_out) {
+    __shared__ float t[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int m = m0 + ty + 8 * r, n = n0 + tx;
+        float a = 0.f;
+        if (m < M && n < N)
+            for (int s = 0; s < nslab; ++s) a += slabs[s * slab_stride + (size_t)m * N + n];
+        t[ty + 8 * r][tx] = a;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int n = n0 + ty + 8 * r, m = m0 + tx;
+        if (n < N && m < M) out[(size_t)n * ld_out + m] = t[tx][ty + 8 * r];
+    }
+}
+
 // several column sums in one launch: problem i sums the M_i rows of X_i (fp32 or bf16) into out_i (and out2_i)
 struct ColsumBatch { VqaColsumDesc d[VQA_COLSUM_MAX]; int first_block[VQA_COLSUM_MAX + 1]; int n; };
 
@@ -1058,6 +1081,15 @@ int vqa_slab_sum_multi(const VqaSlabSumDesc* descs, int n, hipStream_t stream) {
     batch.first_block[n] = blocks;
     k_slab_sum_multi<<<blocks, 256, 0, stream>>>(batch);
     return vqa_check_launch("vqa_slab_sum_multi");
+}
+
+int vqa_slab_sum_transpose(const float* slabs, int nslab, size_t slab_stride, int M, int N, float* out, int ld_out,
+                           hipStream_t stream) {
+    VQA_REQUIRE(slabs && out && nslab >= 1 && M >= 0 && N >= 0 && ld_out >= M, "vqa_slab_sum_transpose: bad arguments");
+    VQA_REQUIRE(nslab == 1 || slab_stride >= (size_t)M * N, "vqa_slab_sum_transpose: slab_stride too small");
+    if (M == 0 || N == 0) return 0;
+    k_slab_sum_transpose<<<dim3((N + 31) / 32, (M + 31) / 32), 256, 0, stream>>>(slabs, nslab, slab_stride, M, N, out, ld_out);
+    return vqa_check_launch("vqa_slab_sum_transpose");
 }
 
 int vqa_colsum_multi(const VqaColsumDesc* descs, int n, hipStream_t stream) {

@@ -362,9 +362,14 @@ class _VQAHeadModel(nn.Module):
              ptr(addend), ld_add, act, ptr(out_pre), ld_pre, ptr(out_post), ld_post,
              self.dt if post_dtype is None else post_dtype, seed, p)
 
-    def _wgrad(self, dy, ld_dy, x, ldx, wname, M, N, K, active_k=None, defer=False):
+    def _wgrad(self, dy, ld_dy, x, ldx, wname, M, N, K, active_k=None, defer=False, swapped=False):
         """grad(W)[M,N] = dy^T x with dy stored [K][M], x stored [K][N].  defer: the split-K partial sums go to
-        an arena of their own and are reduced later, together with the other deferred ones, by _flush_wgrads()."""
+        an arena of their own and are reduced later, together with the other deferred ones, by _flush_wgrads().
+        swapped: the product runs as x^T dy (N x M) and the split-K reduction transposes it back."""
+        if swapped:
+            slab, sk, stride = self._gemm_slabs(x, ldx, 0, dy, ld_dy, 0, N, M, K, active_k=active_k)
+            call('vqa_slab_sum_transpose', ptr(slab), sk, stride, N, M, ptr(self._g(wname)), N)
+            return
         sk = call('vqa_gemm_splitk_hint', M, N, K, 0, 0)
         if sk == 1:                 # a single K range: the product is the gradient, written in place
             call('vqa_gemm_slabs_rows', ptr(dy), ld_dy, 0, ptr(x), ldx, 0, ptr(self._g(wname)), M * N, N, M, N, K, 1,
@@ -875,6 +880,7 @@ class VQAAttnModel(_VQAHeadModel):
                 ws[f'u32_{k}'] = z((B, H), f32)
                 ws[f'uT_{k}'] = z((B, H), tdt)
 
+    swap_big_wgrad = True    # dW_va is computed as its transpose (the faster operand orientation) and transposed by the reduce
     fuse_row_norm = True     # the first hop's projection computes the region norms itself (one pass over the features less)
 
     def _visual_prologue(self, ws, feats, B):
@@ -939,7 +945,7 @@ class VQAAttnModel(_VQAHeadModel):
                 if du_carry is not None:
                     self._add_dq(ws, B, du_carry, 1, 0)
             self._bucket_done(pre + 'linear_va.bias')
-            self._wgrad(ws['dP'], A, feats, Dv, pre + 'linear_va.weight', A, Dv, B * R)
+            self._wgrad(ws['dP'], A, feats, Dv, pre + 'linear_va.weight', A, Dv, B * R, swapped=self.swap_big_wgrad)
             self._bucket_done(pre + 'linear_va.weight')
             if k > 0:
                 slab, sk, st = self._gemm_slabs(ws['duT'], H, 1, self._w(ppre + 'linear_u.weight'), Dv, 0, B, Dv, H)
