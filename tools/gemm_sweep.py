@@ -32,6 +32,10 @@ if __name__ == '__main__':
             run('square', 8192, 8192, 8192, True, True, [(6, 1), (8, 1), (9, 1)])
             run('wgrad TN', 1200, 2048, 50176, False, False, [(6, 6), (8, 6), (9, 6), (4, 3), (6, 5), (6, 7)])
             run('wgrad TN swapped', 2048, 1200, 50176, False, False, [(6, 6), (8, 6), (4, 3)])
+    elif which == 'xg':
+        for _ in range(2):
+            for M in (1920, 2048, 3584):
+                run('xg proj', M, 9600, 624, True, True, [(2, 1), (3, 1), (4, 1), (6, 1), (9, 1)])
     else:
         for _ in range(2):
             run('classif2 fwd', 256, 3000, 256, True, True, [(2, 1), (3, 1)])
