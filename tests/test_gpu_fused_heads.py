@@ -28,7 +28,7 @@ def test_epilogue_fusion_matches_two_launches(dtype, B, F, pad, sk):
     assert 0.3 < float((x_b[:, :F] != 0).float().mean()) < 0.7
 
 
-@pytest.mark.parametrize('M,N,sk', [(2048, 1200, 6), (33, 65, 1), (1, 7, 3), (100, 31, 2)])
+@pytest.mark.parametrize('M,N,sk', [(2048, 1200, 6), (33, 65, 1), (1, 7, 3), (100, 31, 2), (100, 36, 2), (4, 4, 1), (68, 132, 3)])
 def test_slab_sum_transpose(M, N, sk):
     g = torch.Generator(device='cuda').manual_seed(M + N)
     slabs = torch.randn(sk, M, N, device='cuda', generator=g)

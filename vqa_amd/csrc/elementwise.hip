@@ -522,6 +522,34 @@ __global__ void __launch_bounds__(256) k_slab_sum_transpose(const float* __restr
     }
 }
 
+// The same on 64 x 64 tiles with 16-byte accesses on both sides (M, N, ld_out multiples of 4, 16-byte aligned bases).
+__global__ void __launch_bounds__(256) k_slab_sum_transpose4(const float* __restrict__ slabs, int nslab, size_t slab_stride,
+                                                             int M, int N, float* __restrict__ out, int ld_out) {
+    __shared__ float t[64][65];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;          // 16 x 16
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int ml = ty + 16 * r, m = m0 + ml, n = n0 + tx * 4;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        if (m < M && n < N) {
+            a = *reinterpret_cast<const f32x4*>(slabs + (size_t)m * N + n);
+            for (int s = 1; s < nslab; ++s) a += *reinterpret_cast<const f32x4*>(slabs + s * slab_stride + (size_t)m * N + n);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t[ml][tx * 4 + e] = a[e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int nl = ty + 16 * r, n = n0 + nl, m = m0 + tx * 4;
+        if (n < N && m < M) {
+            const f32x4 v = {t[tx * 4][nl], t[tx * 4 + 1][nl], t[tx * 4 + 2][nl], t[tx * 4 + 3][nl]};
+            *reinterpret_cast<f32x4*>(out + (size_t)n * ld_out + m) = v;
+        }
+    }
+}
+
 // several column sums in one launch: problem i sums the M_i rows of X_i (fp32 or bf16) into out_i (and out2_i)
 struct ColsumBatch { VqaColsumDesc d[VQA_COLSUM_MAX]; int first_block[VQA_COLSUM_MAX + 1]; int n; };
 
@@ -1088,7 +1116,10 @@ int vqa_slab_sum_transpose(const float* slabs, int nslab, size_t slab_stride, in
     VQA_REQUIRE(slabs && out && nslab >= 1 && M >= 0 && N >= 0 && ld_out >= M, "vqa_slab_sum_transpose: bad arguments");
     VQA_REQUIRE(nslab == 1 || slab_stride >= (size_t)M * N, "vqa_slab_sum_transpose: slab_stride too small");
     if (M == 0 || N == 0) return 0;
-    k_slab_sum_transpose<<<dim3((N + 31) / 32, (M + 31) / 32), 256, 0, stream>>>(slabs, nslab, slab_stride, M, N, out, ld_out);
+    const bool vec = M % 4 == 0 && N % 4 == 0 && ld_out % 4 == 0 && (slab_stride & 3) == 0 &&
+                     ((((uintptr_t)slabs) | ((uintptr_t)out)) & 15) == 0;
+    if (vec) k_slab_sum_transpose4<<<dim3((N + 63) / 64, (M + 63) / 64), 256, 0, stream>>>(slabs, nslab, slab_stride, M, N, out, ld_out);
+    else k_slab_sum_transpose<<<dim3((N + 31) / 32, (M + 31) / 32), 256, 0, stream>>>(slabs, nslab, slab_stride, M, N, out, ld_out);
     return vqa_check_launch("vqa_slab_sum_transpose");
 }
 
