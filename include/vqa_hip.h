@@ -181,6 +181,15 @@ int vqa_gemm_splitk_hint(int M, int N, int K, int a_kmajor, int b_kmajor);
 int vqa_gemm_slabs(const void* A, int lda, int a_kmajor, const void* B, int ldb, int b_kmajor, float* slabs,
                    size_t slab_stride, int ld_slab, int M, int N, int K, int splitk, int dtype, int engine,
                    hipStream_t stream);
+/* Up to 4 independent products of the same operand layout in one launch (each product of the head is a few
+ * microseconds of work and a dependent launch costs about as much): slabs as above, 64 x 64 tiles for bf16;
+ * fp32 runs them one after the other. */
+typedef struct {
+    const void* A; int lda; const void* B; int ldb;
+    float* slabs; size_t slab_stride; int ld_slab;
+    int M, N, K, splitk;
+} VqaGemmDesc;
+int vqa_gemm_slabs_group(const VqaGemmDesc* descs, int n, int a_kmajor, int b_kmajor, int dtype, hipStream_t stream);
 /* The same two products restricted to the first *active_rows rows of the output (a device-side
  * count read by the kernel: workgroups whose first row is past it exit; rows past it inside a
  * started tile may or may not be written) and, for the slab form, to the first *active_k terms of

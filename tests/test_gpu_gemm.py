@@ -132,3 +132,28 @@ def test_projection_with_fused_row_norm(M, N, K, out_dtype):
     call('vqa_inv_norm', ptr(As), ptr(inv2), M, K, lda, BF16)
     torch.cuda.synchronize()
     assert float(((inv - inv2).abs() / inv2).max()) <= 1e-5
+
+
+@pytest.mark.parametrize('akm,bkm', [(1, 1), (0, 0), (1, 0)])
+def test_grouped_small_products(akm, bkm):
+    """Up to four independent products in one launch give exactly what the single launches give (64 x 64 tiles)."""
+    from vqa_amd import _lib
+    shapes = [(256, 1200, 2400, 6), (256, 1208, 2400, 6), (37, 50, 72, 1), (300, 129, 64, 3)]
+    ops, problems, singles = [], [], []
+    for i, (M, N, K, sk) in enumerate(shapes):
+        As, lda, Bs, ldb, ref = make(M, N, K, akm, bkm, torch.bfloat16, 40 + i)
+        grouped = torch.full((sk, M, N), float('nan'), device='cuda')
+        single = torch.full((sk, M, N), float('nan'), device='cuda')
+        call('vqa_gemm_slabs', ptr(As), lda, akm, ptr(Bs), ldb, bkm, ptr(single), M * N, N, M, N, K, sk, BF16, 2)
+        problems.append((ptr(As), lda, ptr(Bs), ldb, ptr(grouped), M * N, N, M, N, K, sk))
+        ops.append((As, Bs, ref, grouped, single))
+    for n in (4, 1, 3):
+        for _, _, _, grouped, _ in ops:
+            grouped.fill_(float('nan'))
+        _lib.gemm_slabs_group(problems[:n], akm, bkm, BF16)
+        torch.cuda.synchronize()
+        for _, _, ref, grouped, single in ops[:n]:
+            assert torch.equal(grouped, single)
+            assert float((grouped.double().sum(0) - ref).abs().max() / ref.abs().max()) <= 2e-5
+    with pytest.raises(_lib.VqaHipError):
+        _lib.gemm_slabs_group(problems + problems[:1], akm, bkm, BF16)

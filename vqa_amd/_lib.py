@@ -48,6 +48,7 @@ _SIGNATURES = {
     'vqa_gemm_splitk_hint': [_i, _i, _i, _i, _i],
     'vqa_gemm_slabs': [_p, _i, _i, _p, _i, _i, _p, _z, _i, _i, _i, _i, _i, _i, _i, _p],
     'vqa_gemm_slabs_rows': [_p, _i, _i, _p, _i, _i, _p, _z, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p],
+    'vqa_gemm_slabs_group': [_p, _i, _i, _i, _i, _p],
     'vqa_slab_sum_transpose': [_p, _i, _z, _i, _i, _p, _i, _p],
     'vqa_epilogue_fusion': [_p, _i, _z, _i, _i, _p, _p, _p, _p, _i, _u, _f, _i, _p],
     'vqa_gemm_fused_rownorm': [_p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _p, _i, _i, _i, _i, _p],
@@ -154,6 +155,22 @@ def slab_sum_multi(problems):
     for d, (slabs, nslab, stride, count, out) in zip(arr, problems):
         d.slabs, d.nslab, d.slab_stride, d.count, d.out = slabs, nslab, stride, count, ptr(out)
     return call('vqa_slab_sum_multi', arr, len(problems))
+
+
+class GemmDesc(C.Structure):
+    """VqaGemmDesc of include/vqa_hip.h."""
+    _fields_ = [('A', C.c_void_p), ('lda', C.c_int), ('B', C.c_void_p), ('ldb', C.c_int),
+                ('slabs', C.c_void_p), ('slab_stride', C.c_size_t), ('ld_slab', C.c_int),
+                ('M', C.c_int), ('N', C.c_int), ('K', C.c_int), ('splitk', C.c_int)]
+
+
+def gemm_slabs_group(problems, akm: int, bkm: int, dtype: int):
+    """problems: iterable of (A address, lda, B address, ldb, slab address, slab_stride, ld_slab, M, N, K, splitk)."""
+    arr = (GemmDesc * len(problems))()
+    for d, (A, lda, B, ldb, slabs, stride, ld_slab, M, N, K, sk) in zip(arr, problems):
+        d.A, d.lda, d.B, d.ldb, d.slabs, d.slab_stride, d.ld_slab = A, lda, B, ldb, slabs, stride, ld_slab
+        d.M, d.N, d.K, d.splitk = M, N, K, sk
+    return call('vqa_gemm_slabs_group', arr, len(problems), akm, bkm, dtype)
 
 
 def dtype_code(dt: torch.dtype) -> int:

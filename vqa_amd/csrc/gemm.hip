@@ -58,14 +58,18 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 // Logical workgroup id (or -1: nothing to do) and the number of output tiles per K split.  With a
 // device-side row limit only the row tiles below it count, and the XCD remap is applied to that
 // smaller set so that the live tiles stay spread over all eight XCDs.
-__device__ __forceinline__ int logical_block(const Epi& epi, int bm, int tiles_m, int tiles_n, bool remap, int& tiles) {
+__device__ __forceinline__ int logical_block(const Epi& epi, int bm, int tiles_m, int tiles_n, bool remap, int& tiles,
+                                             int bid, int grid) {
     int tm = tiles_m;
-    const int nsplit = gridDim.x / (tiles_m * tiles_n);
+    const int nsplit = grid / (tiles_m * tiles_n);
     if (epi.m_limit) tm = min(tiles_m, (*epi.m_limit + bm - 1) / bm);
     tiles = tm * tiles_n;
     const int nblk = tiles * nsplit;
-    if ((int)blockIdx.x >= nblk) return -1;
-    return remap ? xcd_remap(blockIdx.x, nblk) : (int)blockIdx.x;
+    if (bid >= nblk) return -1;
+    return remap ? xcd_remap(bid, nblk) : bid;
+}
+__device__ __forceinline__ int logical_block(const Epi& epi, int bm, int tiles_m, int tiles_n, bool remap, int& tiles) {
+    return logical_block(epi, bm, tiles_m, tiles_n, remap, tiles, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // ---- LDS tile images ---------------------------------------------------------------
@@ -276,10 +280,11 @@ __device__ __forceinline__ void epilogue_store(char* lds, f32x4 (&acc)[MT][NT], 
     }
 }
 
+// One workgroup's share (an output tile of one K split) of a product; `bid` of `grid` workgroups work on it.
 template <int BM, int BN, bool AKM, bool BKM>
-__global__ void __launch_bounds__(256)
-k_gemm_bf16(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, int M, int N, int K,
-            int tiles_m, int tiles_n, int k_per_split, Epi epi) {
+__device__ __forceinline__ void gemm_bf16_workgroup(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb,
+                                                    int M, int N, int K, int tiles_m, int tiles_n, int k_per_split,
+                                                    const Epi& epi, int bid, int grid) {
     typedef Tile<BM, AKM> TA;
     typedef Tile<BN, BKM> TB;
     constexpr int STAGE = TA::BYTES + TB::BYTES;
@@ -291,7 +296,7 @@ k_gemm_bf16(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B,
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wm = wave >> 1, wn = wave & 1;
     int tiles;
-    const int L = logical_block(epi, BM, tiles_m, tiles_n, true, tiles);
+    const int L = logical_block(epi, BM, tiles_m, tiles_n, true, tiles, bid, grid);
     if (L < 0) return;                                   // uniform over the workgroup, before any barrier
     const int split = L / tiles, ti = L % tiles;
     const int m0 = (ti / tiles_n) * BM, n0 = (ti % tiles_n) * BN;
@@ -367,6 +372,37 @@ k_gemm_bf16(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B,
     }
 
     epilogue_store<MT, NT>(lds, acc, epi, split, m0 + wm * (BM / 2), n0 + wn * (BN / 2), M, N, wave, lane);
+}
+
+template <int BM, int BN, bool AKM, bool BKM>
+__global__ void __launch_bounds__(256)
+k_gemm_bf16(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, int M, int N, int K,
+            int tiles_m, int tiles_n, int k_per_split, Epi epi) {
+    gemm_bf16_workgroup<BM, BN, AKM, BKM>(A, lda, B, ldb, M, N, K, tiles_m, tiles_n, k_per_split, epi,
+                                          (int)blockIdx.x, (int)gridDim.x);
+}
+
+// Several independent small products (64 x 64 tiles, fp32 partial sums) in one launch: each product costs a
+// dependent launch about 4.5 us whatever its size, and small ones do not fill the chip on their own.
+#define VQA_GEMM_GROUP_MAX 4
+struct GemmGroup {
+    const bf16_t* A[VQA_GEMM_GROUP_MAX]; const bf16_t* B[VQA_GEMM_GROUP_MAX]; float* out[VQA_GEMM_GROUP_MAX];
+    size_t split_stride[VQA_GEMM_GROUP_MAX];
+    int lda[VQA_GEMM_GROUP_MAX], ldb[VQA_GEMM_GROUP_MAX], ldo[VQA_GEMM_GROUP_MAX];
+    int M[VQA_GEMM_GROUP_MAX], N[VQA_GEMM_GROUP_MAX], K[VQA_GEMM_GROUP_MAX];
+    int tiles_m[VQA_GEMM_GROUP_MAX], tiles_n[VQA_GEMM_GROUP_MAX], kps[VQA_GEMM_GROUP_MAX];
+    int first_block[VQA_GEMM_GROUP_MAX + 1];
+    int n;
+};
+
+template <bool AKM, bool BKM>
+__global__ void __launch_bounds__(256) k_gemm_bf16_group(GemmGroup g) {
+    int p = 0;
+    while (p + 1 < g.n && (int)blockIdx.x >= g.first_block[p + 1]) ++p;
+    Epi epi{g.out[p], g.ldo[p], 0, g.split_stride[p], nullptr, nullptr, 0, nullptr, nullptr, nullptr};
+    gemm_bf16_workgroup<64, 64, AKM, BKM>(g.A[p], g.lda[p], g.B[p], g.ldb[p], g.M[p], g.N[p], g.K[p], g.tiles_m[p],
+                                          g.tiles_n[p], g.kps[p], epi, (int)blockIdx.x - g.first_block[p],
+                                          g.first_block[p + 1] - g.first_block[p]);
 }
 
 // ---- 256 x 128 workgroup tile, 8 waves, 3-stage LDS ring ------------------------------------
@@ -892,6 +928,43 @@ int vqa_gemm_slabs_rows(const void* A, int lda, int a_kmajor, const void* B, int
     else if (dtype == VQA_BF16) launch_valu<bf16_t>(A, lda, a_kmajor, B, ldb, b_kmajor, M, N, K, splitk, epi, stream);
     else launch_valu<float>(A, lda, a_kmajor, B, ldb, b_kmajor, M, N, K, splitk, epi, stream);
     return vqa_check_launch("vqa_gemm_slabs");
+}
+
+int vqa_gemm_slabs_group(const VqaGemmDesc* descs, int n, int a_kmajor, int b_kmajor, int dtype, hipStream_t stream) {
+    VQA_REQUIRE(descs && n >= 1 && n <= VQA_GEMM_GROUP_MAX, "vqa_gemm_slabs_group: 1..4 products");
+    bool mfma = dtype == VQA_BF16;
+    for (int i = 0; i < n; ++i) {
+        const VqaGemmDesc& d = descs[i];
+        if (int rc = gemm_check(d.A, d.lda, a_kmajor, d.B, d.ldb, b_kmajor, d.M, d.N, d.K, dtype, 0)) return rc;
+        VQA_REQUIRE(d.slabs && d.splitk >= 1 && d.splitk <= 64 && d.ld_slab >= d.N, "vqa_gemm_slabs_group: bad slab arguments");
+        VQA_REQUIRE(d.splitk == 1 || d.slab_stride >= (size_t)d.M * d.ld_slab, "vqa_gemm_slabs_group: slab_stride too small");
+    }
+    if (!mfma) {                         // fp32: the products one after the other
+        for (int i = 0; i < n; ++i) {
+            const VqaGemmDesc& d = descs[i];
+            if (int rc = vqa_gemm_slabs(d.A, d.lda, a_kmajor, d.B, d.ldb, b_kmajor, d.slabs, d.slab_stride, d.ld_slab, d.M, d.N,
+                                        d.K, d.splitk, dtype, 0, stream)) return rc;
+        }
+        return 0;
+    }
+    GemmGroup g;
+    g.n = n;
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        const VqaGemmDesc& d = descs[i];
+        g.A[i] = (const bf16_t*)d.A; g.B[i] = (const bf16_t*)d.B; g.out[i] = d.slabs; g.split_stride[i] = d.slab_stride;
+        g.lda[i] = d.lda; g.ldb[i] = d.ldb; g.ldo[i] = d.ld_slab; g.M[i] = d.M; g.N[i] = d.N; g.K[i] = d.K;
+        g.tiles_m[i] = ceil_div(d.M, 64); g.tiles_n[i] = ceil_div(d.N, 64);
+        g.kps[i] = ceil_div(ceil_div(d.K, d.splitk), GEMM_BK) * GEMM_BK;
+        g.first_block[i] = blocks;
+        blocks += g.tiles_m[i] * g.tiles_n[i] * d.splitk;
+    }
+    g.first_block[n] = blocks;
+    if (a_kmajor && b_kmajor) k_gemm_bf16_group<true, true><<<blocks, 256, 0, stream>>>(g);
+    else if (a_kmajor && !b_kmajor) k_gemm_bf16_group<true, false><<<blocks, 256, 0, stream>>>(g);
+    else if (!a_kmajor && b_kmajor) k_gemm_bf16_group<false, true><<<blocks, 256, 0, stream>>>(g);
+    else k_gemm_bf16_group<false, false><<<blocks, 256, 0, stream>>>(g);
+    return vqa_check_launch("vqa_gemm_slabs_group");
 }
 
 int vqa_gemm_slabs(const void* A, int lda, int a_kmajor, const void* B, int ldb, int b_kmajor, float* slabs,

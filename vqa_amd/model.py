@@ -386,6 +386,51 @@ class _VQAHeadModel(nn.Module):
         call('vqa_epilogue', ptr(slab), sk, stride, M, N, None, None, None, 0, 0, ptr(self._g(wname)), N,
              None, 0, _lib.F32, 0, 0.0)
 
+    def _wgrad_grouped(self, items):
+        """Several weight gradients (dy, ld_dy, x, ldx, wname, M, N, K), each grad(W)[M,N] = dy^T x, as one launch
+        when their contraction is short; a product with one K range is written straight into the gradient buffer,
+        the others leave partial sums for _flush_wgrads()."""
+        if self.dt != _lib.BF16 or any(K > 512 for *_, K in items) or len(items) > 4:
+            for dy, ld_dy, x, ldx, wname, M, N, K in items:
+                self._wgrad(dy, ld_dy, x, ldx, wname, M, N, K, defer=True)
+            return
+        problems = []
+        for dy, ld_dy, x, ldx, wname, M, N, K in items:
+            sk = call('vqa_gemm_splitk_hint', M, N, K, 0, 0)
+            if sk == 1:
+                addr = ptr(self._g(wname))
+            else:
+                addr = self._arena(sk * M * N, dy.device)
+                self._wgrad_pending.append((addr, sk, M * N, M * N, self._g(wname)))
+            problems.append((ptr(dy), ld_dy, ptr(x), ldx, addr, M * N, N, M, N, K, sk))
+        _lib.gemm_slabs_group(problems, 0, 0, self.dt)
+
+    def _q_side_products(self, ws):
+        """Forward products whose input is ready as soon as the question is encoded: (key, x, ldx, weight name, N, K).
+        They run as one launch before the image side; their partial sums wait in ws['early'] for the epilogue."""
+        return [('linear_q', ws['q_d'], self.Hq, 'linear_q.weight', self.F, self.Hq)]
+
+    def _launch_early(self, ws, B):
+        items = self._q_side_products(ws)
+        ws['early'] = {}
+        if self.dt != _lib.BF16 or not items:
+            return
+        problems, off = [], 0
+        sizes = []
+        for key, x, ldx, wname, N, K in items:
+            sk = call('vqa_gemm_splitk_hint', B, N, K, 1, 1)
+            sizes.append((sk, sk * B * N))
+        total = sum(n for _, n in sizes)
+        buf = ws.get('early_buf')
+        if buf is None or buf.numel() < total:
+            buf = ws['early_buf'] = torch.empty(total, dtype=torch.float32, device=x.device)
+        for (key, x, ldx, wname, N, K), (sk, n) in zip(items, sizes):
+            addr = buf.data_ptr() + 4 * off
+            off += n
+            problems.append((ptr(x), ldx, ptr(self._w(wname)), K, addr, B * N, N, B, N, K, sk))
+            ws['early'][key] = (addr, sk, B * N)
+        _lib.gemm_slabs_group(problems, 1, 1, self.dt)
+
     def _arena(self, nfloats: int, device) -> int:
         """Address of nfloats floats that stay untouched until _flush_wgrads()."""
         if self._wslab is None or self._wslab.device != device or self._wslab_off + nfloats > self._wslab.numel():
@@ -559,13 +604,18 @@ class _VQAHeadModel(nn.Module):
         self._visual_prologue(ws, feats, B)
         self._finish_pending()
         self._refresh_shadow()
-        self._visual_forward(ws, feats, B, seeds[0], p)           # -> ws['pooled_d'] = dropout(visual vector)
         if self.seq2vec.arch == '2-lstm':       # (the single-layer encoder's cell kernel wrote q_d already)
             call('vqa_dropout', ptr(ws['qT']), H, ptr(ws['q_d']), H, B, H, seeds[1], p, dt)
+        self._launch_early(ws, B)                                  # question-side products of the head, one launch
+        self._visual_forward(ws, feats, B, seeds[0], p)           # -> ws['pooled_d'] = dropout(visual vector)
         self._linear(ws['pooled_d'], Dv, 'linear_v.weight', 'linear_v.bias', B, F, Dv, act=1, out_pre=ws['xv'], ld_pre=F)
         # xq = tanh(linear_q(q)) and the fusion x = dropout(tanh(xv * xq)) in the launch that reduces linear_q's slabs
-        slab, sk, st = self._gemm_slabs(ws['q_d'], H, 1, self._w('linear_q.weight'), H, 1, B, F, H)
-        call('vqa_epilogue_fusion', ptr(slab), sk, st, B, F, ptr(self._f32('linear_q.bias')), ptr(ws['xv']), ptr(ws['xq']),
+        if 'linear_q' in ws['early']:
+            slab, sk, st = ws['early']['linear_q']
+        else:
+            slab, sk, st = self._gemm_slabs(ws['q_d'], H, 1, self._w('linear_q.weight'), H, 1, B, F, H)
+            slab = ptr(slab)
+        call('vqa_epilogue_fusion', slab, sk, st, B, F, ptr(self._f32('linear_q.bias')), ptr(ws['xv']), ptr(ws['xq']),
              ptr(ws['x']), F + Ec, seeds[2], p, dt)
         if Ec:
             call('vqa_caption_pool', ptr(captions), ptr(self._cap_t), ptr(ws['x']), B, Tc, Ec, Ec,
@@ -594,10 +644,8 @@ class _VQAHeadModel(nn.Module):
         _lib.bind_stream()
         g = self._g
         # classifier
-        self._wgrad(ws['dlogits'], Cp, ws['h1d'], Hf, 'linear_classif2.weight', C, Hf, B, defer=True)
         slab, sk, st = self._gemm_slabs(ws['dlogits'], Cp, 1, self._w('linear_classif2.weight'), Hf, 0, B, Hf, C)
         call('vqa_tanh_dropout_bwd', ptr(slab), sk, st, ptr(ws['h1t']), Hf, ptr(ws['dz1']), Hf, B, Hf, seeds[3], p, dt)
-        self._wgrad(ws['dz1'], Hf, ws['x'], F + Ec, 'linear_classif1.weight', Hf, F + Ec, B, defer=True)
         # fusion
         slab, sk, st = self._gemm_slabs(ws['dz1'], Hf, 1, self._w('linear_classif1.weight'), F + Ec, 0, B, F + Ec, Hf)
         call('vqa_fusion_bwd', ptr(slab), sk, st, F + Ec, ptr(ws['xv']), ptr(ws['xq']), ptr(ws['dzv']), ptr(ws['dzq']),
@@ -609,9 +657,11 @@ class _VQAHeadModel(nn.Module):
                            (ws['dz1'], Hf, B, Hf, dt, g('linear_classif1.bias'), None),
                            (ws['dzv'], F, B, F, dt, g('linear_v.bias'), None),
                            (ws['dzq'], F, B, F, dt, g('linear_q.bias'), None)])
-        self._wgrad(ws['dzv'], F, ws['pooled_d'], Dv, 'linear_v.weight', F, Dv, B, defer=True)
-        self._wgrad(ws['dzq'], F, ws['q_d'], H, 'linear_q.weight', F, H, B, defer=True)
-        self._flush_wgrads()                      # the head's four weight gradients reduced in one launch
+        self._wgrad_grouped([(ws['dlogits'], Cp, ws['h1d'], Hf, 'linear_classif2.weight', C, Hf, B),
+                             (ws['dz1'], Hf, ws['x'], F + Ec, 'linear_classif1.weight', Hf, F + Ec, B),
+                             (ws['dzv'], F, ws['pooled_d'], Dv, 'linear_v.weight', F, Dv, B),
+                             (ws['dzq'], F, ws['q_d'], H, 'linear_q.weight', F, H, B)])   # the head's four weight gradients: one launch
+        self._flush_wgrads()                      # (those with split K: partial sums reduced in one launch)
         self._bucket_done('linear_q.bias')
         slab, sk, st = self._gemm_slabs(ws['dzv'], F, 1, self._w('linear_v.weight'), Dv, 0, B, Dv, F)
         call('vqa_epilogue', ptr(slab), sk, st, B, Dv, None, None, None, 0, 0, None, 0, ptr(ws['d_pooled']), Dv,
@@ -853,6 +903,10 @@ class VQAAttnModel(_VQAHeadModel):
             out += [f'attention.{k}.linear_a.weight', f'attention.{k}.linear_va.weight']
         return out
 
+    def _q_side_products(self, ws):
+        # the first hop's query projection reads the question vector itself
+        return super()._q_side_products(ws) + [('qa0', ws['qT'], self.Hq, 'attention.0.linear_qa.weight', self.A, self.Hq)]
+
     def _prepare_visual(self, input_v):
         if input_v.dim() == 4:                       # (B, Dv, H, W) as model.py:159 produces
             B, Dv, Hh, Ww = input_v.shape
@@ -900,7 +954,12 @@ class VQAAttnModel(_VQAHeadModel):
             else:
                 call('vqa_gemm_fused', ptr(feats), Dv, 1, ptr(self._w(pre + 'linear_va.weight')), Dv, 1, ptr(ws[f'P{k}']), A,
                      B * R, A, Dv, ptr(self._f32(pre + 'linear_va.bias')), ptr(ws['inv_norm']), 0, dt, dt, self.gemm_engine)
-            self._linear(uT, H, pre + 'linear_qa.weight', pre + 'linear_qa.bias', B, A, H, out_pre=ws[f'qa{k}'], ld_pre=A)
+            if k == 0 and 'qa0' in ws['early']:
+                slab, sk, st = ws['early']['qa0']
+                call('vqa_epilogue', slab, sk, st, B, A, ptr(self._f32(pre + 'linear_qa.bias')), None, None, 0, 0,
+                     ptr(ws['qa0']), A, None, 0, dt, 0, 0.0)
+            else:
+                self._linear(uT, H, pre + 'linear_qa.weight', pre + 'linear_qa.bias', B, A, H, out_pre=ws[f'qa{k}'], ld_pre=A)
             ev = self._event_pair('attn_fwd')
             call('vqa_attn_fwd', ptr(ws[f'P{k}']), A, ptr(feats), Dv, ptr(ws[f'qa{k}']), A,
                  ptr(self._f32(pre + 'linear_a.weight')), ptr(self._f32(pre + 'linear_a.bias')), ptr(ws['inv_norm']),
