@@ -236,6 +236,12 @@ int vqa_fusion_fwd(const float* xv, const float* xq, void* x, int ldx, int B, in
 int vqa_epilogue_fusion(const float* slabs, int nslab, size_t slab_stride, int B, int F, const float* bias,
                         const float* xv, float* xq, void* x, int ldx, unsigned seed, float p, int dtype,
                         hipStream_t stream);
+/* Both branches still in split-K partial sums: xv = tanh(sum sv + bias_v), xq = tanh(sum sq + bias_q) are stored
+ * (B, F) fp32 and x = dropout(tanh(xv * xq)): the two reductions and the fusion in one launch.   model.py:63-73 */
+int vqa_fusion_fwd_slabs(const float* slabs_v, int nslab_v, size_t stride_v, const float* bias_v,
+                         const float* slabs_q, int nslab_q, size_t stride_q, const float* bias_q,
+                         float* xv, float* xq, void* x, int ldx, int B, int F, unsigned seed, float p, int dtype,
+                         hipStream_t stream);
 /* backward of the above down to the pre-activations of linear_v / linear_q (xv, xq are
  * the stored tanh outputs): dzv = dx drop (1-t^2) xq (1-xv^2), dzq likewise */
 int vqa_fusion_bwd(const float* slabs, int nslab, size_t slab_stride, int ldslab, const float* xv, const float* xq,

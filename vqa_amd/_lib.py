@@ -50,6 +50,7 @@ _SIGNATURES = {
     'vqa_gemm_slabs_rows': [_p, _i, _i, _p, _i, _i, _p, _z, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p],
     'vqa_gemm_slabs_group': [_p, _i, _i, _i, _i, _p],
     'vqa_slab_sum_transpose': [_p, _i, _z, _i, _i, _p, _i, _p],
+    'vqa_fusion_fwd_slabs': [_p, _i, _z, _p, _p, _i, _z, _p, _p, _p, _p, _i, _i, _i, _u, _f, _i, _p],
     'vqa_epilogue_fusion': [_p, _i, _z, _i, _i, _p, _p, _p, _p, _i, _u, _f, _i, _p],
     'vqa_gemm_fused_rownorm': [_p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _p, _i, _i, _i, _i, _p],
     'vqa_gemm_fused_rows': [_p, _i, _i, _p, _i, _i, _p, _i, _i, _i, _i, _p, _p, _i, _i, _i, _i, _p, _p],

@@ -410,6 +410,27 @@ __global__ void k_fusion_fwd(const float* __restrict__ xv, const float* __restri
     }
 }
 
+// fusion forward straight from the split-K partial sums of both branches:
+//   xv = tanh(sum_s sv + bv), xq = tanh(sum_s sq + bq) (both stored, fp32), x = dropout(tanh(xv * xq))
+template <typename T>
+__global__ void k_fusion_fwd_slabs(const float* __restrict__ sv, int nv, size_t stride_v, const float* __restrict__ bv,
+                                   const float* __restrict__ sq, int nq, size_t stride_q, const float* __restrict__ bq,
+                                   float* __restrict__ xv, float* __restrict__ xq, T* __restrict__ x, int ldx, int B, int F,
+                                   unsigned seed, unsigned thr, float dscale) {
+    const long total = (long)B * F;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / F), f = (int)(i % F);
+        float a = 0.f, c = 0.f;
+        for (int s = 0; s < nv; ++s) a += sv[s * stride_v + i];
+        for (int s = 0; s < nq; ++s) c += sq[s * stride_q + i];
+        a = Act<T>::tanh_(a + bv[f]);
+        c = Act<T>::tanh_(c + bq[f]);
+        xv[i] = a;
+        xq[i] = c;
+        x[(size_t)b * ldx + f] = from_f32<T>(Act<T>::tanh_(a * c) * drop_mult(seed, (unsigned)i, thr, dscale));
+    }
+}
+
 // fusion backward: dx = sum_s slab (first F of ldslab columns) is d loss / d x
 //   dxf  = dx * dropout * (1 - tanh(xv xq)^2)
 //   dzv  = dxf * xq * (1 - xv^2)      (pre-activation grad of linear_v)
@@ -1060,6 +1081,21 @@ int vqa_epilogue_fusion(const float* slabs, int nslab, size_t slab_stride, int B
                                                      (bf16_t*)x, ldx, seed, thr, ds, xv);
     else return vqa_set_error(-22, "vqa_epilogue_fusion: dtype");
     return vqa_check_launch("vqa_epilogue_fusion");
+}
+
+int vqa_fusion_fwd_slabs(const float* slabs_v, int nslab_v, size_t stride_v, const float* bias_v,
+                         const float* slabs_q, int nslab_q, size_t stride_q, const float* bias_q,
+                         float* xv, float* xq, void* x, int ldx, int B, int F, unsigned seed, float p, int dtype,
+                         hipStream_t stream) {
+    VQA_REQUIRE(slabs_v && slabs_q && nslab_v >= 1 && nslab_q >= 1 && bias_v && bias_q && xv && xq && x && B >= 0 && F > 0 &&
+                ldx >= F, "vqa_fusion_fwd_slabs: bad arguments");
+    VQA_REQUIRE(p >= 0.f && p < 1.f, "vqa_fusion_fwd_slabs: p must be in [0, 1)");
+    if (B == 0) return 0;
+    const unsigned thr = drop_threshold(p);
+    const float ds = 1.0f / (1.0f - p);
+    DISPATCH_T(dtype, (k_fusion_fwd_slabs<T><<<grid_for((long)B * F, 256), 256, 0, stream>>>(
+        slabs_v, nslab_v, stride_v, bias_v, slabs_q, nslab_q, stride_q, bias_q, xv, xq, (T*)x, ldx, B, F, seed, thr, ds)));
+    return vqa_check_launch("vqa_fusion_fwd_slabs");
 }
 
 int vqa_fusion_bwd(const float* slabs, int nslab, size_t slab_stride, int ldslab, const float* xv, const float* xq,

@@ -608,15 +608,24 @@ class _VQAHeadModel(nn.Module):
             call('vqa_dropout', ptr(ws['qT']), H, ptr(ws['q_d']), H, B, H, seeds[1], p, dt)
         self._launch_early(ws, B)                                  # question-side products of the head, one launch
         self._visual_forward(ws, feats, B, seeds[0], p)           # -> ws['pooled_d'] = dropout(visual vector)
-        self._linear(ws['pooled_d'], Dv, 'linear_v.weight', 'linear_v.bias', B, F, Dv, act=1, out_pre=ws['xv'], ld_pre=F)
-        # xq = tanh(linear_q(q)) and the fusion x = dropout(tanh(xv * xq)) in the launch that reduces linear_q's slabs
+        # xv = tanh(linear_v(v)), xq = tanh(linear_q(q)) and the fusion x = dropout(tanh(xv * xq)): one launch reduces
+        # both products' partial sums (linear_q's wait in ws['early'] or, failing that, share the slab workspace)
+        skv = call('vqa_gemm_splitk_hint', B, F, Dv, 1, 1)
         if 'linear_q' in ws['early']:
-            slab, sk, st = ws['early']['linear_q']
+            qslab, skq, stq = ws['early']['linear_q']
+            nfl = skv * B * F
         else:
-            slab, sk, st = self._gemm_slabs(ws['q_d'], H, 1, self._w('linear_q.weight'), H, 1, B, F, H)
-            slab = ptr(slab)
-        call('vqa_epilogue_fusion', slab, sk, st, B, F, ptr(self._f32('linear_q.bias')), ptr(ws['xv']), ptr(ws['xq']),
-             ptr(ws['x']), F + Ec, seeds[2], p, dt)
+            skq = call('vqa_gemm_splitk_hint', B, F, H, 1, 1)
+            nfl = (skv + skq) * B * F
+        buf = self._slabs(nfl, ws['pooled_d'].device)
+        call('vqa_gemm_slabs_rows', ptr(ws['pooled_d']), Dv, 1, ptr(self._w('linear_v.weight')), Dv, 1, ptr(buf), B * F, F,
+             B, F, Dv, skv, self.dt, self.gemm_engine, None, None)
+        if 'linear_q' not in ws['early']:
+            qslab, stq = buf.data_ptr() + 4 * skv * B * F, B * F
+            call('vqa_gemm_slabs_rows', ptr(ws['q_d']), H, 1, ptr(self._w('linear_q.weight')), H, 1, qslab, stq, F,
+                 B, F, H, skq, self.dt, self.gemm_engine, None, None)
+        call('vqa_fusion_fwd_slabs', ptr(buf), skv, B * F, ptr(self._f32('linear_v.bias')), qslab, skq, stq,
+             ptr(self._f32('linear_q.bias')), ptr(ws['xv']), ptr(ws['xq']), ptr(ws['x']), F + Ec, B, F, seeds[2], p, dt)
         if Ec:
             call('vqa_caption_pool', ptr(captions), ptr(self._cap_t), ptr(ws['x']), B, Tc, Ec, Ec,
                  self._cap_t.shape[0], F + Ec, F, dt)
