@@ -133,6 +133,21 @@ int vqa_attn_bwd(const void* P, int ldP, const void* V, int ldV, const float* qa
                  const float* inv_norm, const float* p_in, const float* d_pooled, int ld_dpool, void* dP, int ld_dP,
                  float* dqa_f32, void* dqa_t, int ld_dqa, float* dwa_part, float* dc_part, int B, int R, int A, int Dv,
                  int dtype, hipStream_t stream);
+/* The same two kernels fed with split-K partial sums instead of a reduced operand (a launch less each):
+ * forward: qa = sum_s qa_slabs[s] + qa_bias is formed by the kernel's prologue and stored to qa (B, A);
+ * backward: d_pooled = (sum_s dpool_slabs[s]) * dropout mask of (drop_seed, drop_p) on a (B, Dv) matrix is formed
+ * by the prologue (d_pooled is scratch).  Shapes outside the bf16 streaming kernels reduce with vqa_epilogue first.
+ * No reference counterpart, as above. */
+int vqa_attn_fwd_qslabs(const void* P, int ldP, const void* V, int ldV, const float* qa_slabs, int qa_nslab,
+                        size_t qa_stride, const float* qa_bias, float* qa, int ld_qa, const float* w_a,
+                        const float* c_a, const float* inv_norm, float* p_out, void* pooled_t, float* pooled_f32,
+                        int ld_pool, int B, int R, int A, int Dv, int dtype, void* pooled_drop, unsigned drop_seed,
+                        float drop_p, hipStream_t stream);
+int vqa_attn_bwd_dslabs(const void* P, int ldP, const void* V, int ldV, const float* qa, int ld_qa, const float* w_a,
+                        const float* inv_norm, const float* p_in, const float* dpool_slabs, int dpool_nslab,
+                        size_t dpool_stride, unsigned drop_seed, float drop_p, float* d_pooled, int ld_dpool, void* dP,
+                        int ld_dP, float* dqa_f32, void* dqa_t, int ld_dqa, float* dwa_part, float* dc_part, int B, int R,
+                        int A, int Dv, int dtype, hipStream_t stream);
 
 /* ---- feature-map front-ends of the reference's ResNet models (precomputed maps) ------------- */
 

@@ -111,3 +111,46 @@ def test_attn_bwd_bf16_shapes(B, R, A, Dv):
     else:
         assert float(dP.float().abs().max()) <= 1e-6 and float(dqa.abs().max()) <= 1e-6
     assert float(dc.double().sum().abs()) <= 1e-4 * max(1.0, float(dpool.abs().max()))
+
+
+@pytest.mark.parametrize('B,R,A,Dv', [(4, 196, 1200, 2048), (2, 17, 24, 72), (2, 50, 1200, 4096)])
+def test_attention_fed_with_partial_sums_matches_reduced_operands(B, R, A, Dv):
+    """vqa_attn_fwd_qslabs / vqa_attn_bwd_dslabs = vqa_epilogue + vqa_attn_fwd / vqa_attn_bwd, bit for bit
+    (streaming kernels: the prologue reduces; Dv = 4096: the entry reduces first)."""
+    from vqa_amd._lib import call, ptr, BF16, F32
+    g = torch.Generator(device='cuda').manual_seed(B + R)
+    dt = torch.bfloat16
+    P = torch.randn(B, R, A, device='cuda', generator=g).to(dt)
+    V = torch.randn(B, R, Dv, device='cuda', generator=g).clamp_min(0).to(dt)
+    wa = torch.randn(A, device='cuda', generator=g) * (2.0 / A ** 0.5)
+    c = torch.zeros(1, device='cuda')
+    inv = torch.rand(B, R, device='cuda', generator=g) + 0.5
+    qs = torch.randn(3, B, A, device='cuda', generator=g) * 0.5
+    qb = torch.randn(A, device='cuda', generator=g)
+    dsl = torch.randn(2, B, Dv, device='cuda', generator=g)
+    outs = []
+    for fused in (False, True):
+        qa = torch.zeros(B, A, device='cuda')
+        p = torch.zeros(B, R, device='cuda')
+        pooled = torch.zeros(B, Dv, device='cuda', dtype=dt)
+        pd = torch.zeros(B, Dv, device='cuda', dtype=dt)
+        dpool = torch.zeros(B, Dv, device='cuda')
+        dP = torch.zeros(B, R, A, device='cuda', dtype=dt)
+        dqa = torch.zeros(B, A, device='cuda'); dqa_t = torch.zeros(B, A, device='cuda', dtype=dt)
+        dwa = torch.zeros(B, A, device='cuda'); dc = torch.zeros(B, device='cuda')
+        if fused:
+            call('vqa_attn_fwd_qslabs', ptr(P), A, ptr(V), Dv, ptr(qs), 3, B * A, ptr(qb), ptr(qa), A, ptr(wa), ptr(c),
+                 ptr(inv), ptr(p), ptr(pooled), None, Dv, B, R, A, Dv, BF16, ptr(pd), 99, 0.5)
+            call('vqa_attn_bwd_dslabs', ptr(P), A, ptr(V), Dv, ptr(qa), A, ptr(wa), ptr(inv), ptr(p), ptr(dsl), 2, B * Dv,
+                 321, 0.5, ptr(dpool), Dv, ptr(dP), A, ptr(dqa), ptr(dqa_t), A, ptr(dwa), ptr(dc), B, R, A, Dv, BF16)
+        else:
+            call('vqa_epilogue', ptr(qs), 3, B * A, B, A, ptr(qb), None, None, 0, 0, ptr(qa), A, None, 0, BF16, 0, 0.0)
+            call('vqa_attn_fwd', ptr(P), A, ptr(V), Dv, ptr(qa), A, ptr(wa), ptr(c), ptr(inv), ptr(p), ptr(pooled), None,
+                 Dv, B, R, A, Dv, BF16, ptr(pd), 99, 0.5)
+            call('vqa_epilogue', ptr(dsl), 2, B * Dv, B, Dv, None, None, None, 0, 0, None, 0, ptr(dpool), Dv, F32, 321, 0.5)
+            call('vqa_attn_bwd', ptr(P), A, ptr(V), Dv, ptr(qa), A, ptr(wa), ptr(inv), ptr(p), ptr(dpool), Dv, ptr(dP), A,
+                 ptr(dqa), ptr(dqa_t), A, ptr(dwa), ptr(dc), B, R, A, Dv, BF16)
+        torch.cuda.synchronize()
+        outs.append((qa, p, pooled, pd, dP, dqa, dqa_t, dwa, dc))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)

@@ -45,6 +45,8 @@ _SIGNATURES = {
     'vqa_attn_lds_bytes': [_i, _i, _i],
     'vqa_attn_fwd': [_p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _u, _f, _p],
     'vqa_attn_bwd': [_p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _i, _p, _i, _p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _p],
+    'vqa_attn_fwd_qslabs': [_p, _i, _p, _i, _p, _i, _z, _p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _u, _f, _p],
+    'vqa_attn_bwd_dslabs': [_p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _i, _z, _u, _f, _p, _i, _p, _i, _p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _p],
     'vqa_gemm_splitk_hint': [_i, _i, _i, _i, _i],
     'vqa_gemm_slabs': [_p, _i, _i, _p, _i, _i, _p, _z, _i, _i, _i, _i, _i, _i, _i, _p],
     'vqa_gemm_slabs_rows': [_p, _i, _i, _p, _i, _i, _p, _z, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p],

@@ -477,7 +477,9 @@ k_attn_fwd_online(const bf16_t* __restrict__ P, int ldP, const bf16_t* __restric
                   const float* __restrict__ qa, int ld_qa, const float* __restrict__ w_a,
                   const float* __restrict__ c_a, const float* __restrict__ inv_norm, float* __restrict__ p_out,
                   bf16_t* __restrict__ pooled_t, float* __restrict__ pooled_f32, int ld_pool, int R, int A, int Dv,
-                  bf16_t* __restrict__ pooled_drop, unsigned seed, unsigned thr, float dscale) {
+                  bf16_t* __restrict__ pooled_drop, unsigned seed, unsigned thr, float dscale,
+                  const float* __restrict__ q_slabs = nullptr, int q_nslab = 0, size_t q_stride = 0,
+                  const float* __restrict__ q_bias = nullptr, float* __restrict__ qa_out = nullptr) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int R4 = (R + 3) & ~3;
     float* s_s = smem;                       // scores
@@ -496,7 +498,19 @@ k_attn_fwd_online(const bf16_t* __restrict__ P, int ldP, const bf16_t* __restric
     const int nch = (R + CH - 1) / CH;
 
     const float kk = 2.8853900817779268f;                 // 2 * log2(e)
-    for (int a = tid; a < A; a += ATT_THREADS) { red[a] = qa[(size_t)b * ld_qa + a] * kk; red[A + a] = 2.f * w_a[a]; }
+    for (int a = tid; a < A; a += ATT_THREADS) {
+        float v;
+        if (q_slabs) {          // the query projection is still in split-K partial sums: reduce it here and store it
+            v = 0.f;
+            for (int s2 = 0; s2 < q_nslab; ++s2) v += q_slabs[s2 * q_stride + (size_t)b * A + a];
+            if (q_bias) v += q_bias[a];
+            qa_out[(size_t)b * ld_qa + a] = v;
+        } else {
+            v = qa[(size_t)b * ld_qa + a];
+        }
+        red[a] = v * kk;
+        red[A + a] = 2.f * w_a[a];
+    }
     for (int r = tid; r < R4 + 16; r += ATT_THREADS) {
         wn_s[r] = r < R ? inv_norm[(size_t)b * R + r] : 0.f;
         s_s[r] = -INFINITY;
@@ -626,7 +640,9 @@ k_attn_bwd_pipe(const bf16_t* __restrict__ P, int ldP, const bf16_t* __restrict_
                 const float* __restrict__ inv_norm, const float* __restrict__ p_in,
                 const float* __restrict__ d_pooled, int ld_dpool, bf16_t* __restrict__ dP, int ld_dP,
                 float* __restrict__ dqa_f32, bf16_t* __restrict__ dqa_t, int ld_dqa, float* __restrict__ dwa_part,
-                float* __restrict__ dc_part, int R, int A, int Dv) {
+                float* __restrict__ dc_part, int R, int A, int Dv,
+                const float* __restrict__ d_slabs = nullptr, int d_nslab = 0, size_t d_stride = 0,
+                unsigned d_seed = 0, unsigned d_thr = 0, float d_scale = 1.f) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* dpool_s = smem;
     float* ds_s = dpool_s + Dv;
@@ -641,7 +657,17 @@ k_attn_bwd_pipe(const bf16_t* __restrict__ P, int ldP, const bf16_t* __restrict_
     bf16_t* dPb = dP + (size_t)b * R * ld_dP;
     const int nv = Dv >> 3, nva = A >> 3;
 
-    for (int d = tid; d < Dv; d += ATT_THREADS) dpool_s[d] = d_pooled[(size_t)b * ld_dpool + d];
+    for (int d = tid; d < Dv; d += ATT_THREADS) {
+        float v;
+        if (d_slabs) {          // d pooled is still in split-K partial sums (and before its dropout): reduce it here
+            v = 0.f;
+            for (int s2 = 0; s2 < d_nslab; ++s2) v += d_slabs[s2 * d_stride + (size_t)b * Dv + d];
+            v *= drop_mult(d_seed, (unsigned)(b * Dv + d), d_thr, d_scale);
+        } else {
+            v = d_pooled[(size_t)b * ld_dpool + d];
+        }
+        dpool_s[d] = v;
+    }
     for (int r = tid; r < R; r += ATT_THREADS) wn_s[r] = inv_norm[(size_t)b * R + r];
     __syncthreads();
 
@@ -800,10 +826,12 @@ static int attn_check(int B, int R, int A, int Dv, int ldP, int ldV) {
     return 0;
 }
 
-int vqa_attn_fwd(const void* P, int ldP, const void* V, int ldV, const float* qa, int ld_qa, const float* w_a,
-                 const float* c_a, const float* inv_norm, float* p_out, void* pooled_t, float* pooled_f32,
-                 int ld_pool, int B, int R, int A, int Dv, int dtype, void* pooled_drop, unsigned drop_seed,
-                 float drop_p, hipStream_t stream) {
+// q_slabs != nullptr: the query projection arrives as split-K partial sums (+ bias) and is written to qa
+static int attn_fwd_impl(const void* P, int ldP, const void* V, int ldV, const float* qa, int ld_qa, const float* w_a,
+                         const float* c_a, const float* inv_norm, float* p_out, void* pooled_t, float* pooled_f32,
+                         int ld_pool, int B, int R, int A, int Dv, int dtype, void* pooled_drop, unsigned drop_seed,
+                         float drop_p, const float* q_slabs, int q_nslab, size_t q_stride, const float* q_bias,
+                         hipStream_t stream) {
     VQA_REQUIRE(P && V && qa && w_a && c_a && inv_norm && p_out && (pooled_t || pooled_f32), "vqa_attn_fwd: null pointer");
     VQA_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "vqa_attn_fwd: drop_p must be in [0, 1)");
     const unsigned thr = drop_threshold(drop_p);
@@ -813,7 +841,13 @@ int vqa_attn_fwd(const void* P, int ldP, const void* V, int ldV, const float* qa
     if (B == 0) return 0;
     const size_t lds = ((size_t)2 * A + R + ((R + 3) & ~3) + (size_t)ATT_THREADS * 8) * sizeof(float);
     const int nva_l = (A / 8 + 63) / 64;
-    if (dtype == VQA_BF16 && Dv / 8 <= 256 && nva_l <= 4 && ATT_ONLINE) {
+    const bool online = dtype == VQA_BF16 && Dv / 8 <= 256 && nva_l <= 4 && ATT_ONLINE;
+    if (q_slabs && !online) {            // the other kernels take the reduced projection: reduce it first
+        if (int rc = vqa_epilogue(q_slabs, q_nslab, q_stride, B, A, q_bias, nullptr, nullptr, 0, 0, const_cast<float*>(qa),
+                                  ld_qa, nullptr, 0, VQA_F32, 0, 0.f, stream)) return rc;
+        q_slabs = nullptr;
+    }
+    if (online) {
         const size_t r4 = (size_t)((R + 3) & ~3);
         const size_t fa = (size_t)2 * A, fc = (size_t)ATT_THREADS * 8;
         const size_t lds_o = (2 * (r4 + 16) + (fa > fc ? fa : fc)) * sizeof(float);
@@ -822,7 +856,8 @@ int vqa_attn_fwd(const void* P, int ldP, const void* V, int ldV, const float* qa
     if (lds_o > 48 * 1024)                                                                                         \
         VQA_REQUIRE(hipFuncSetAttribute((const void*)k_attn_fwd_online<NVA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_o) == hipSuccess, "vqa_attn_fwd: cannot reserve LDS"); \
     k_attn_fwd_online<NVA><<<B, ATT_THREADS, lds_o, stream>>>((const bf16_t*)P, ldP, (const bf16_t*)V, ldV, qa, \
-        ld_qa, w_a, c_a, inv_norm, p_out, (bf16_t*)pooled_t, pooled_f32, ld_pool, R, A, Dv, (bf16_t*)pooled_drop, drop_seed, thr, dsc); \
+        ld_qa, w_a, c_a, inv_norm, p_out, (bf16_t*)pooled_t, pooled_f32, ld_pool, R, A, Dv, (bf16_t*)pooled_drop, drop_seed, thr, dsc, \
+        q_slabs, q_nslab, q_stride, q_bias, const_cast<float*>(qa)); \
   }
         if (nva_l == 1) ATT_FWD_ONLINE(1) else if (nva_l == 2) ATT_FWD_ONLINE(2) else if (nva_l == 3) ATT_FWD_ONLINE(3) else ATT_FWD_ONLINE(4)
 #undef ATT_FWD_ONLINE
@@ -853,10 +888,31 @@ int vqa_attn_fwd(const void* P, int ldP, const void* V, int ldV, const float* qa
     return vqa_check_launch("vqa_attn_fwd");
 }
 
-int vqa_attn_bwd(const void* P, int ldP, const void* V, int ldV, const float* qa, int ld_qa, const float* w_a,
-                 const float* inv_norm, const float* p_in, const float* d_pooled, int ld_dpool, void* dP, int ld_dP,
-                 float* dqa_f32, void* dqa_t, int ld_dqa, float* dwa_part, float* dc_part, int B, int R, int A, int Dv,
-                 int dtype, hipStream_t stream) {
+int vqa_attn_fwd(const void* P, int ldP, const void* V, int ldV, const float* qa, int ld_qa, const float* w_a,
+                 const float* c_a, const float* inv_norm, float* p_out, void* pooled_t, float* pooled_f32,
+                 int ld_pool, int B, int R, int A, int Dv, int dtype, void* pooled_drop, unsigned drop_seed,
+                 float drop_p, hipStream_t stream) {
+    return attn_fwd_impl(P, ldP, V, ldV, qa, ld_qa, w_a, c_a, inv_norm, p_out, pooled_t, pooled_f32, ld_pool, B, R, A, Dv,
+                         dtype, pooled_drop, drop_seed, drop_p, nullptr, 0, 0, nullptr, stream);
+}
+
+int vqa_attn_fwd_qslabs(const void* P, int ldP, const void* V, int ldV, const float* qa_slabs, int qa_nslab,
+                        size_t qa_stride, const float* qa_bias, float* qa, int ld_qa, const float* w_a,
+                        const float* c_a, const float* inv_norm, float* p_out, void* pooled_t, float* pooled_f32,
+                        int ld_pool, int B, int R, int A, int Dv, int dtype, void* pooled_drop, unsigned drop_seed,
+                        float drop_p, hipStream_t stream) {
+    VQA_REQUIRE(qa_slabs && qa_nslab >= 1 && (qa_nslab == 1 || qa_stride >= (size_t)B * A), "vqa_attn_fwd_qslabs: bad partial sums");
+    return attn_fwd_impl(P, ldP, V, ldV, qa, ld_qa, w_a, c_a, inv_norm, p_out, pooled_t, pooled_f32, ld_pool, B, R, A, Dv,
+                         dtype, pooled_drop, drop_seed, drop_p, qa_slabs, qa_nslab, qa_stride, qa_bias, stream);
+}
+
+// d_slabs != nullptr: d pooled arrives as split-K partial sums still to be multiplied by the dropout mask of
+// (d_seed, d_p); d_pooled is then scratch for the kernels that need it reduced
+static int attn_bwd_impl(const void* P, int ldP, const void* V, int ldV, const float* qa, int ld_qa, const float* w_a,
+                         const float* inv_norm, const float* p_in, const float* d_pooled, int ld_dpool, void* dP, int ld_dP,
+                         float* dqa_f32, void* dqa_t, int ld_dqa, float* dwa_part, float* dc_part, int B, int R, int A, int Dv,
+                         int dtype, const float* d_slabs, int d_nslab, size_t d_stride, unsigned d_seed, float d_p,
+                         hipStream_t stream) {
     VQA_REQUIRE(P && V && qa && w_a && inv_norm && p_in && d_pooled && dP && dqa_f32 && dwa_part, "vqa_attn_bwd: null pointer");
     if (int rc = attn_check(B, R, A, Dv, ldP, ldV)) return rc;
     VQA_REQUIRE(ld_qa >= A && ld_dpool >= Dv && ld_dP >= A && ld_dP % 8 == 0 && ld_dqa >= A, "vqa_attn_bwd: leading dimension too small");
@@ -864,13 +920,23 @@ int vqa_attn_bwd(const void* P, int ldP, const void* V, int ldV, const float* qa
     const size_t r4 = (size_t)((R + 3) & ~3);
     const size_t lds = ((size_t)Dv + 2 * r4 + (size_t)ATT_THREADS * 8) * sizeof(float);
     const int nvd_l = (Dv / 8 + 63) / 64;
-    if (dtype == VQA_BF16 && A / 8 <= ATT_THREADS && nvd_l <= 4 && ((ld_qa & 3) == 0) && ((((uintptr_t)qa | (uintptr_t)w_a) & 15) == 0)) {
+    const bool pipe = dtype == VQA_BF16 && A / 8 <= ATT_THREADS && nvd_l <= 4 && ((ld_qa & 3) == 0) && ((((uintptr_t)qa | (uintptr_t)w_a) & 15) == 0);
+    VQA_REQUIRE(d_p >= 0.f && d_p < 1.f, "vqa_attn_bwd: dropout probability must be in [0, 1)");
+    const unsigned d_thr = drop_threshold(d_p);
+    const float d_scale = 1.0f / (1.0f - d_p);
+    if (d_slabs && !pipe) {
+        if (int rc = vqa_epilogue(d_slabs, d_nslab, d_stride, B, Dv, nullptr, nullptr, nullptr, 0, 0, nullptr, 0,
+                                  const_cast<float*>(d_pooled), ld_dpool, VQA_F32, d_seed, d_p, stream)) return rc;
+        d_slabs = nullptr;
+    }
+    if (pipe) {
 #define ATT_BWD_PIPE(NVD)                                                                                          \
   {                                                                                                                \
     if (lds > 48 * 1024)                                                                                           \
         VQA_REQUIRE(hipFuncSetAttribute((const void*)k_attn_bwd_pipe<NVD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess, "vqa_attn_bwd: cannot reserve LDS"); \
     k_attn_bwd_pipe<NVD><<<B, ATT_THREADS, lds, stream>>>((const bf16_t*)P, ldP, (const bf16_t*)V, ldV, qa, ld_qa, w_a,  \
-        inv_norm, p_in, d_pooled, ld_dpool, (bf16_t*)dP, ld_dP, dqa_f32, (bf16_t*)dqa_t, ld_dqa, dwa_part, dc_part, R, A, Dv); \
+        inv_norm, p_in, d_pooled, ld_dpool, (bf16_t*)dP, ld_dP, dqa_f32, (bf16_t*)dqa_t, ld_dqa, dwa_part, dc_part, R, A, Dv, \
+        d_slabs, d_nslab, d_stride, d_seed, d_thr, d_scale); \
   }
         if (nvd_l == 1) ATT_BWD_PIPE(1) else if (nvd_l == 2) ATT_BWD_PIPE(2) else if (nvd_l == 3) ATT_BWD_PIPE(3) else ATT_BWD_PIPE(4)
 #undef ATT_BWD_PIPE
@@ -888,6 +954,26 @@ int vqa_attn_bwd(const void* P, int ldP, const void* V, int ldV, const float* qa
                                                            ld_dqa, dwa_part, dc_part, R, A, Dv);
     } else return vqa_set_error(-22, "vqa_attn_bwd: dtype");
     return vqa_check_launch("vqa_attn_bwd");
+}
+
+int vqa_attn_bwd(const void* P, int ldP, const void* V, int ldV, const float* qa, int ld_qa, const float* w_a,
+                 const float* inv_norm, const float* p_in, const float* d_pooled, int ld_dpool, void* dP, int ld_dP,
+                 float* dqa_f32, void* dqa_t, int ld_dqa, float* dwa_part, float* dc_part, int B, int R, int A, int Dv,
+                 int dtype, hipStream_t stream) {
+    return attn_bwd_impl(P, ldP, V, ldV, qa, ld_qa, w_a, inv_norm, p_in, d_pooled, ld_dpool, dP, ld_dP, dqa_f32, dqa_t,
+                         ld_dqa, dwa_part, dc_part, B, R, A, Dv, dtype, nullptr, 0, 0, 0, 0.f, stream);
+}
+
+int vqa_attn_bwd_dslabs(const void* P, int ldP, const void* V, int ldV, const float* qa, int ld_qa, const float* w_a,
+                        const float* inv_norm, const float* p_in, const float* dpool_slabs, int dpool_nslab,
+                        size_t dpool_stride, unsigned drop_seed, float drop_p, float* d_pooled, int ld_dpool, void* dP,
+                        int ld_dP, float* dqa_f32, void* dqa_t, int ld_dqa, float* dwa_part, float* dc_part, int B, int R,
+                        int A, int Dv, int dtype, hipStream_t stream) {
+    VQA_REQUIRE(dpool_slabs && dpool_nslab >= 1 && (dpool_nslab == 1 || dpool_stride >= (size_t)B * Dv),
+                "vqa_attn_bwd_dslabs: bad partial sums");
+    return attn_bwd_impl(P, ldP, V, ldV, qa, ld_qa, w_a, inv_norm, p_in, d_pooled, ld_dpool, dP, ld_dP, dqa_f32, dqa_t,
+                         ld_dqa, dwa_part, dc_part, B, R, A, Dv, dtype, dpool_slabs, dpool_nslab, dpool_stride, drop_seed,
+                         drop_p, stream);
 }
 
 }  // extern "C"

@@ -111,6 +111,8 @@ class _VQAHeadModel(nn.Module):
     classes; a subclass supplies the visual front-end that turns its image input into the
     (B, Dv) vector entering ``linear_v`` (hooks ``_build_visual`` ... ``_visual_backward``)."""
 
+    _dpool_from_slabs = False   # the front end's backward takes d(visual vector) as split-K partial sums
+
     def __init__(self, vocab_questions: Sequence[str], vocab_answers: Sequence[str], args=None,
                  input_size: int = 512, *, dtype: torch.dtype = torch.bfloat16, emb_size: int = 620,
                  question_out: int = QUESTION_OUT, visual_out: int = VISUAL_OUT,
@@ -673,8 +675,14 @@ class _VQAHeadModel(nn.Module):
         self._flush_wgrads()                      # (those with split K: partial sums reduced in one launch)
         self._bucket_done('linear_q.bias')
         slab, sk, st = self._gemm_slabs(ws['dzv'], F, 1, self._w('linear_v.weight'), Dv, 0, B, Dv, F)
-        call('vqa_epilogue', ptr(slab), sk, st, B, Dv, None, None, None, 0, 0, None, 0, ptr(ws['d_pooled']), Dv,
-             _lib.F32, seeds[0], p)
+        if self._dpool_from_slabs and not self.train_encoder:
+            # the attention backward kernel reduces these partial sums (and applies dropoutV's mask) in its prologue;
+            # nothing else touches the slab workspace before it runs
+            ws['dpool_src'] = (ptr(slab), sk, st, seeds[0], p)
+        else:
+            ws['dpool_src'] = None
+            call('vqa_epilogue', ptr(slab), sk, st, B, Dv, None, None, None, 0, 0, None, 0, ptr(ws['d_pooled']), Dv,
+                 _lib.F32, seeds[0], p)
         if self.train_encoder:                  # d loss / d q through linear_q and its dropout (model.py:67-68)
             slab, sk, st = self._gemm_slabs(ws['dzq'], F, 1, self._w('linear_q.weight'), H, 0, B, H, F)
             call('vqa_epilogue', ptr(slab), sk, st, B, H, None, None, None, 0, 0, None, 0, ptr(ws['dq32']), H,
@@ -943,6 +951,7 @@ class VQAAttnModel(_VQAHeadModel):
                 ws[f'u32_{k}'] = z((B, H), f32)
                 ws[f'uT_{k}'] = z((B, H), tdt)
 
+    _dpool_from_slabs = True
     swap_big_wgrad = True    # dW_va is computed as its transpose (the faster operand orientation) and transposed by the reduce
     fuse_row_norm = True     # the first hop's projection computes the region norms itself (one pass over the features less)
 
@@ -963,17 +972,22 @@ class VQAAttnModel(_VQAHeadModel):
             else:
                 call('vqa_gemm_fused', ptr(feats), Dv, 1, ptr(self._w(pre + 'linear_va.weight')), Dv, 1, ptr(ws[f'P{k}']), A,
                      B * R, A, Dv, ptr(self._f32(pre + 'linear_va.bias')), ptr(ws['inv_norm']), 0, dt, dt, self.gemm_engine)
-            if k == 0 and 'qa0' in ws['early']:
-                slab, sk, st = ws['early']['qa0']
-                call('vqa_epilogue', slab, sk, st, B, A, ptr(self._f32(pre + 'linear_qa.bias')), None, None, 0, 0,
-                     ptr(ws['qa0']), A, None, 0, dt, 0, 0.0)
-            else:
+            early = k == 0 and 'qa0' in ws['early']
+            if not early:
                 self._linear(uT, H, pre + 'linear_qa.weight', pre + 'linear_qa.bias', B, A, H, out_pre=ws[f'qa{k}'], ld_pre=A)
             ev = self._event_pair('attn_fwd')
-            call('vqa_attn_fwd', ptr(ws[f'P{k}']), A, ptr(feats), Dv, ptr(ws[f'qa{k}']), A,
-                 ptr(self._f32(pre + 'linear_a.weight')), ptr(self._f32(pre + 'linear_a.bias')), ptr(ws['inv_norm']),
-                 ptr(ws[f'p{k}']), ptr(ws[f'pooled{k}']), None, Dv, B, R, A, Dv, dt,
-                 ptr(ws['pooled_d']) if k + 1 == self.hops else None, seed, p)       # dropoutV fused into the last hop
+            if early:               # the kernel's prologue reduces the query projection's partial sums (+ bias) into qa0
+                slab, sk, st = ws['early']['qa0']
+                call('vqa_attn_fwd_qslabs', ptr(ws[f'P{k}']), A, ptr(feats), Dv, slab, sk, st,
+                     ptr(self._f32(pre + 'linear_qa.bias')), ptr(ws['qa0']), A,
+                     ptr(self._f32(pre + 'linear_a.weight')), ptr(self._f32(pre + 'linear_a.bias')), ptr(ws['inv_norm']),
+                     ptr(ws[f'p{k}']), ptr(ws[f'pooled{k}']), None, Dv, B, R, A, Dv, dt,
+                     ptr(ws['pooled_d']) if k + 1 == self.hops else None, seed, p)
+            else:
+                call('vqa_attn_fwd', ptr(ws[f'P{k}']), A, ptr(feats), Dv, ptr(ws[f'qa{k}']), A,
+                     ptr(self._f32(pre + 'linear_a.weight')), ptr(self._f32(pre + 'linear_a.bias')), ptr(ws['inv_norm']),
+                     ptr(ws[f'p{k}']), ptr(ws[f'pooled{k}']), None, Dv, B, R, A, Dv, dt,
+                     ptr(ws['pooled_d']) if k + 1 == self.hops else None, seed, p)   # dropoutV fused into the last hop
             if ev is not None:
                 ev[1].record()
             if k + 1 < self.hops:
@@ -990,10 +1004,18 @@ class VQAAttnModel(_VQAHeadModel):
         for k in reversed(range(self.hops)):
             pre = f'attention.{k}.'
             uT = ws['qT'] if k == 0 else ws[f'uT_{k}']
-            call('vqa_attn_bwd', ptr(ws[f'P{k}']), A, ptr(feats), Dv, ptr(ws[f'qa{k}']), A,
-                 ptr(self._f32(pre + 'linear_a.weight')), ptr(ws['inv_norm']), ptr(ws[f'p{k}']), ptr(ws['d_pooled']), Dv,
-                 ptr(ws['dP']), A, ptr(ws['dqa32']), ptr(ws['dqaT']), A, ptr(ws['dwa_part']), ptr(ws['dc_part']),
-                 B, R, A, Dv, dt)
+            src = ws.get('dpool_src') if k + 1 == self.hops else None
+            if src is not None:
+                slab, sk, st, dseed, dp = src
+                call('vqa_attn_bwd_dslabs', ptr(ws[f'P{k}']), A, ptr(feats), Dv, ptr(ws[f'qa{k}']), A,
+                     ptr(self._f32(pre + 'linear_a.weight')), ptr(ws['inv_norm']), ptr(ws[f'p{k}']), slab, sk, st, dseed, dp,
+                     ptr(ws['d_pooled']), Dv, ptr(ws['dP']), A, ptr(ws['dqa32']), ptr(ws['dqaT']), A, ptr(ws['dwa_part']),
+                     ptr(ws['dc_part']), B, R, A, Dv, dt)
+            else:
+                call('vqa_attn_bwd', ptr(ws[f'P{k}']), A, ptr(feats), Dv, ptr(ws[f'qa{k}']), A,
+                     ptr(self._f32(pre + 'linear_a.weight')), ptr(ws['inv_norm']), ptr(ws[f'p{k}']), ptr(ws['d_pooled']), Dv,
+                     ptr(ws['dP']), A, ptr(ws['dqa32']), ptr(ws['dqaT']), A, ptr(ws['dwa_part']), ptr(ws['dc_part']),
+                     B, R, A, Dv, dt)
             # the hop's small gradients in one launch: w_a, its offset c, and the two biases that share d(P + qa)
             _lib.colsum_multi([(ws['dwa_part'], A, B, A, _lib.F32, g(pre + 'linear_a.weight'), None),
                                (ws['dc_part'], 1, B, 1, _lib.F32, g(pre + 'linear_a.bias'), None),
