@@ -497,12 +497,33 @@ k_attn_fwd_online(const bf16_t* __restrict__ P, int ldP, const bf16_t* __restric
     const bool pool = grp < G;
     const int nch = (R + CH - 1) / CH;
 
+    int voff[NVA];
+#pragma unroll
+    for (int i = 0; i < NVA; ++i) voff[i] = min(lane + 64 * i, nva - 1) * 8;
+    // row of this wave in chunk k: CH * k + wv; rows of this thread in chunk k: CH * k + grp + G * u, u < 4
+    auto load_p = [&](int k, u32x4_t (&dst)[NVA]) {
+        const bf16_t* row = Pb + (size_t)min(CH * k + wv, R - 1) * ldP;
+#pragma unroll
+        for (int i = 0; i < NVA; ++i) dst[i] = __builtin_bit_cast(u32x4_t, ld_stream(row + voff[i]));
+    };
+    const bf16_t* col = Vb + (pool ? cv : 0) * 8;
+    auto load_v = [&](int k, u32x4_t (&dst)[4]) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            dst[u] = __builtin_bit_cast(u32x4_t, ld_stream(col + (size_t)min(CH * k + grp + G * u, R - 1) * ldV));
+    };
+    // the first chunk of both streams is requested before anything else: the staging below (and, when the query
+    // projection arrives as partial sums, its reduction) runs under the latency of these loads
+    u32x4_t pa[NVA];                                       // P row of the next chunk to score
+    u32x4_t va[4];                                         // V rows of the next chunk to pool
+    load_p(0, pa);
+    load_v(0, va);
+
     const float kk = 2.8853900817779268f;                 // 2 * log2(e)
     for (int a = tid; a < A; a += ATT_THREADS) {
         float v;
         if (q_slabs) {          // the query projection is still in split-K partial sums: reduce it here and store it
-            v = 0.f;
-            for (int s2 = 0; s2 < q_nslab; ++s2) v += q_slabs[s2 * q_stride + (size_t)b * A + a];
+            v = slab_sum(q_slabs + (size_t)b * A + a, q_nslab, q_stride);
             if (q_bias) v += q_bias[a];
             qa_out[(size_t)b * ld_qa + a] = v;
         } else {
@@ -518,13 +539,11 @@ k_attn_fwd_online(const bf16_t* __restrict__ P, int ldP, const bf16_t* __restric
     __syncthreads();
     float qk[NVA][8], w2[NVA][8];
     float wsum = 0.f;
-    int voff[NVA];
 #pragma unroll
     for (int i = 0; i < NVA; ++i) {
         const int v = lane + 64 * i;
         const int vc = min(v, nva - 1);
         const float live = v < nva ? 1.f : 0.f;
-        voff[i] = vc * 8;
         const f32x4 q0 = *reinterpret_cast<const f32x4*>(red + vc * 8), q1 = *reinterpret_cast<const f32x4*>(red + vc * 8 + 4);
         const f32x4 g0 = *reinterpret_cast<const f32x4*>(red + A + vc * 8), g1 = *reinterpret_cast<const f32x4*>(red + A + vc * 8 + 4);
 #pragma unroll
@@ -537,18 +556,6 @@ k_attn_fwd_online(const bf16_t* __restrict__ P, int ldP, const bf16_t* __restric
     wsum = wave_sum(wsum) + c_a[0];
     __syncthreads();                                       // red is reused by the final combine
 
-    // row of this wave in chunk k: CH * k + wv; rows of this thread in chunk k: CH * k + grp + G * u, u < 4
-    auto load_p = [&](int k, u32x4_t (&dst)[NVA]) {
-        const bf16_t* row = Pb + (size_t)min(CH * k + wv, R - 1) * ldP;
-#pragma unroll
-        for (int i = 0; i < NVA; ++i) dst[i] = __builtin_bit_cast(u32x4_t, ld_stream(row + voff[i]));
-    };
-    const bf16_t* col = Vb + (pool ? cv : 0) * 8;
-    auto load_v = [&](int k, u32x4_t (&dst)[4]) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            dst[u] = __builtin_bit_cast(u32x4_t, ld_stream(col + (size_t)min(CH * k + grp + G * u, R - 1) * ldV));
-    };
     auto score = [&](int k, const u32x4_t (&x)[NVA]) {
         float acc = 0.f;
 #pragma unroll
@@ -567,10 +574,6 @@ k_attn_fwd_online(const bf16_t* __restrict__ P, int ldP, const bf16_t* __restric
 
     // one chunk of P rows and one chunk of V rows are always in flight (16 x 2.4 KB + 16 x 4 KB per workgroup);
     // a chunk takes several microseconds, so one chunk of look-ahead covers the HBM latency
-    u32x4_t pa[NVA];                                       // P row of the next chunk to score
-    u32x4_t va[4];                                         // V rows of the next chunk to pool
-    load_p(0, pa);
-    load_v(0, va);
     score(0, pa);
     load_p(1, pa);
     __syncthreads();
@@ -660,8 +663,7 @@ k_attn_bwd_pipe(const bf16_t* __restrict__ P, int ldP, const bf16_t* __restrict_
     for (int d = tid; d < Dv; d += ATT_THREADS) {
         float v;
         if (d_slabs) {          // d pooled is still in split-K partial sums (and before its dropout): reduce it here
-            v = 0.f;
-            for (int s2 = 0; s2 < d_nslab; ++s2) v += d_slabs[s2 * d_stride + (size_t)b * Dv + d];
+            v = slab_sum(d_slabs + (size_t)b * Dv + d, d_nslab, d_stride);
             v *= drop_mult(d_seed, (unsigned)(b * Dv + d), d_thr, d_scale);
         } else {
             v = d_pooled[(size_t)b * ld_dpool + d];

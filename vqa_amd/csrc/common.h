@@ -133,3 +133,18 @@ __device__ __forceinline__ float drop_mult(unsigned int seed, unsigned int idx, 
     if (thr == 0u) return 1.0f;
     return drop_hash(seed, idx) >= thr ? scale : 0.0f;
 }
+
+// Sum over the split-K slabs of one element, in slab order (s = 0, 1, ...) as every consumer does.  The loads of
+// the first eight slabs are issued together (a loop with a run-time trip count would wait for each load before
+// the next add: one memory round trip per slab).
+__device__ __forceinline__ float slab_sum(const float* __restrict__ first, int nslab, size_t stride) {
+    float v[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) v[s] = first[(size_t)min(s, nslab - 1) * stride];
+    float a = 0.f;
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+        if (s < nslab) a += v[s];
+    for (int s = 8; s < nslab; ++s) a += first[(size_t)s * stride];
+    return a;
+}

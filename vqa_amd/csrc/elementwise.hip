@@ -371,8 +371,7 @@ __global__ void k_epilogue(const float* __restrict__ slabs, int nslab, size_t sl
     const long total = (long)M * N;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int m = (int)(i / N), n = (int)(i % N);
-        float v = 0.f;
-        for (int s = 0; s < nslab; ++s) v += slabs[s * slab_stride + i];
+        float v = slab_sum(slabs + i, nslab, slab_stride);
         if (row_scale) v *= row_scale[m];
         if (bias) v += bias[n];
         if (addend) v += addend[(size_t)m * ld_add + n];
@@ -420,9 +419,7 @@ __global__ void k_fusion_fwd_slabs(const float* __restrict__ sv, int nv, size_t 
     const long total = (long)B * F;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int b = (int)(i / F), f = (int)(i % F);
-        float a = 0.f, c = 0.f;
-        for (int s = 0; s < nv; ++s) a += sv[s * stride_v + i];
-        for (int s = 0; s < nq; ++s) c += sq[s * stride_q + i];
+        float a = slab_sum(sv + i, nv, stride_v), c = slab_sum(sq + i, nq, stride_q);
         a = Act<T>::tanh_(a + bv[f]);
         c = Act<T>::tanh_(c + bq[f]);
         xv[i] = a;

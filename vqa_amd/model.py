@@ -952,6 +952,9 @@ class VQAAttnModel(_VQAHeadModel):
                 ws[f'uT_{k}'] = z((B, H), tdt)
 
     _dpool_from_slabs = True
+    # the forward kernel can reduce the query projection's partial sums in its prologue (vqa_attn_fwd_qslabs), but the
+    # launch that saves costs the kernel about as much as it gains (measured: 57 -> 60.7 us against a 4.8 us launch)
+    attn_qa_from_slabs = False
     swap_big_wgrad = True    # dW_va is computed as its transpose (the faster operand orientation) and transposed by the reduce
     fuse_row_norm = True     # the first hop's projection computes the region norms itself (one pass over the features less)
 
@@ -973,7 +976,12 @@ class VQAAttnModel(_VQAHeadModel):
                 call('vqa_gemm_fused', ptr(feats), Dv, 1, ptr(self._w(pre + 'linear_va.weight')), Dv, 1, ptr(ws[f'P{k}']), A,
                      B * R, A, Dv, ptr(self._f32(pre + 'linear_va.bias')), ptr(ws['inv_norm']), 0, dt, dt, self.gemm_engine)
             early = k == 0 and 'qa0' in ws['early']
-            if not early:
+            if early and not self.attn_qa_from_slabs:
+                slab, sk, st = ws['early']['qa0']
+                call('vqa_epilogue', slab, sk, st, B, A, ptr(self._f32(pre + 'linear_qa.bias')), None, None, 0, 0,
+                     ptr(ws['qa0']), A, None, 0, dt, 0, 0.0)
+                early = False
+            elif not early:
                 self._linear(uT, H, pre + 'linear_qa.weight', pre + 'linear_qa.bias', B, A, H, out_pre=ws[f'qa{k}'], ld_pre=A)
             ev = self._event_pair('attn_fwd')
             if early:               # the kernel's prologue reduces the query projection's partial sums (+ bias) into qa0
