@@ -32,6 +32,10 @@ if __name__ == '__main__':
             run('square', 8192, 8192, 8192, True, True, [(6, 1), (8, 1), (9, 1)])
             run('wgrad TN', 1200, 2048, 50176, False, False, [(6, 6), (8, 6), (9, 6), (4, 3), (6, 5), (6, 7)])
             run('wgrad TN swapped', 2048, 1200, 50176, False, False, [(6, 6), (8, 6), (4, 3)])
+    elif which == 'probe':
+        for _ in range(2):
+            run('K4 fwd NT', 50176, 1200, 2048, True, True, [(9, 1)])
+            run('square', 8192, 8192, 8192, True, True, [(9, 1)])
     elif which == 'xg':
         for _ in range(2):
             for M in (1920, 2048, 3584):

@@ -639,23 +639,35 @@ k_gemm_bf16_r10(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict_
     auto compute = [&](const char* la, const char* lb) {  // la: this wave's A quarter, lb: its B quarter
         const int bc = (wn & 1) * 64;
         if (PF) {
+            // Sub-step 0's twelve fragments are read and waited for; sub-step 1's are then requested and land under
+            // the MFMAs of sub-step 0 (the first MFMA sits before that request so that the one wait the compiler
+            // inserts covers sub-step 0 only: with more than 15 LDS reads outstanding its counter model gives up
+            // and waits for everything).
             bf16x8_t fa[2][MT], fb[2][NT];
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
+            for (int j = 0; j < NT; ++j) fb[0][j] = frag_read<128, BKM>(lb, bc + j * 16, 0, lane);
 #pragma unroll
-                for (int j = 0; j < NT; ++j) fb[kk][j] = frag_read<128, BKM>(lb, bc + j * 16, kk, lane);
-#pragma unroll
-                for (int i = 0; i < MT; ++i) fa[kk][i] = frag_read<128, AKM>(la, i * 16, kk, lane);
-            }
+            for (int i = 0; i < MT; ++i) fa[0][i] = frag_read<128, AKM>(la, i * 16, 0, lane);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_setprio(1);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0][0], fb[0][0], acc[0][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
+            for (int j = 0; j < NT; ++j) fb[1][j] = frag_read<128, BKM>(lb, bc + j * 16, 1, lane);
 #pragma unroll
-                for (int i = 0; i < MT; ++i)
+            for (int i = 0; i < MT; ++i) fa[1][i] = frag_read<128, AKM>(la, i * 16, 1, lane);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int j = 0; j < NT; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[kk][i], fb[kk][j], acc[i][j], 0, 0, 0);
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    if (i + j > 0) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0][i], fb[0][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1][i], fb[1][j], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
         } else {
 #pragma unroll
