@@ -495,27 +495,39 @@ k_gemm_bf16_w8(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__
     auto compute = [&](const char* la) {
         const char* lb = la + TA::BYTES;
         if (MT <= 4) {
+            // sub-step 0's fragments are read and (by the wait the compiler puts before the first MFMA) waited for;
+            // sub-step 1's are requested right after that first MFMA and land under the rest of sub-step 0
             bf16x8_t fa[2][MT], fb[2][NT];
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
+            for (int i = 0; i < MT; ++i)
+                if (!IL || i < nl) fa[0][i] = frag_read<BM, AKM>(la, wrow + i * FS, 0, lane);
 #pragma unroll
-                for (int i = 0; i < MT; ++i)
-                    if (!IL || i < nl) fa[kk][i] = frag_read<BM, AKM>(la, wrow + i * FS, kk, lane);
-#pragma unroll
-                for (int j = 0; j < NT; ++j) fb[kk][j] = frag_read<BN, BKM>(lb, wn * 64 + j * 16, kk, lane);
-            }
-            __builtin_amdgcn_sched_barrier(0);     // all fragment reads are issued before the first MFMA
+            for (int j = 0; j < NT; ++j) fb[0][j] = frag_read<BN, BKM>(lb, wn * 64 + j * 16, 0, lane);
+            __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_setprio(1);
+            if (!IL || 0 < nl) acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0][0], fb[0][0], acc[0][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
+            for (int i = 0; i < MT; ++i)
+                if (!IL || i < nl) fa[1][i] = frag_read<BM, AKM>(la, wrow + i * FS, 1, lane);
 #pragma unroll
-                for (int i = 0; i < MT; ++i)
-                    if (!IL || i < nl) {
+            for (int j = 0; j < NT; ++j) fb[1][j] = frag_read<BN, BKM>(lb, wn * 64 + j * 16, 1, lane);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int j = 0; j < NT; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[kk][i], fb[kk][j], acc[i][j], 0, 0, 0);
-                    }
-            }
+            for (int i = 0; i < MT; ++i)
+                if (!IL || i < nl) {
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        if (i + j > 0) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0][i], fb[0][j], acc[i][j], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+                if (!IL || i < nl) {
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1][i], fb[1][j], acc[i][j], 0, 0, 0);
+                }
             __builtin_amdgcn_s_setprio(0);
         } else {
             // 128 x 64 per wave: fragments of one K sub-step at a time (register budget)
