@@ -123,3 +123,40 @@ def test_cfg4_caption_stream_full_width():
     po = {k: v.to(torch.bfloat16).float() for k, v in p.items()}
     ref = vqa_ref.forward(po, feats[:4].float(), b['tokens'][:4], b['captions'][:4])
     assert rel_err(logits[:4], ref) <= 1e-2
+
+
+def test_cfg2_fast_paths_agree_with_plain_paths(full_model):
+    """Config 2, one train-mode forward + backward with every fused fast path on (row norms inside the projection
+    GEMM, the big weight gradient in the swapped orientation, grouped small products, partial sums reduced in the
+    consumers' prologues) against the same step with the separate-kernel paths: same loss and gradients to bf16
+    rounding of the intermediate activations (the fused norm sums its squares in a different order)."""
+    from vqa_amd.model import VQAAttnModel
+    m, p = full_model
+    b = vqa_ref.synthetic_batch(256, 196, 2048, 14, FULL['vq'], FULL['C'], seed=77)
+    feats, tok, ans = b['feats'].to(torch.bfloat16).cuda(), b['tokens'].cuda(), b['answers'].cuda()
+    grads = []
+    for fast in (True, False):
+        mm = VQAAttnModel(['w'] * FULL['vq'], ['a'] * FULL['C'], None, dtype=torch.bfloat16, seed=5)
+        mm.load_state_dict(p)
+        mm = mm.to('cuda').train()
+        mm.fuse_row_norm = fast
+        mm.swap_big_wgrad = fast
+        mm._dpool_from_slabs = fast
+        if not fast:
+            mm._launch_early = lambda ws, B: ws.__setitem__('early', {})
+            mm._wgrad_grouped = lambda items: [mm._wgrad(*it, defer=True) for it in items]
+        logits = mm(feats, tok)
+        loss = torch.nn.functional.cross_entropy(logits.float(), ans)
+        loss.backward()
+        torch.cuda.synchronize()
+        grads.append((float(loss.detach()), {k: v.grad.detach().float().cpu().clone() for k, v in mm.named_parameters()
+                                     if v.grad is not None}))
+    (la, ga), (lb, gb) = grads
+    assert abs(la - lb) <= 1e-3 * abs(lb)
+    assert set(ga) == set(gb) and len(ga) >= 14
+    for k in ga:
+        if k.endswith('linear_a.bias'):
+            continue                                  # a sum of zero-mean rounding noise
+        num = float((ga[k] - gb[k]).norm())
+        den = float(gb[k].norm())
+        assert num <= 2e-2 * den + 1e-12, (k, num, den)
