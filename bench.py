@@ -79,6 +79,8 @@ def main():
     ap.add_argument('--hops', type=int, default=1)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-fuse-norm', action='store_true', help='A/B: separate row-norm pass before the image projection')
+    ap.add_argument('--no-fold-embedding', action='store_true',
+                    help='A/B: gather embeddings and run the LSTM input projection every step instead of the per-token table')
     ap.add_argument('--no-swap-wgrad', action='store_true', help='A/B: dW_va in the nn.Linear orientation')
     ap.add_argument('--rccl-single', action='store_true',
                     help='N=1 only: run the bucketed all-reduce path over a one-rank RCCL group (its cost without peers)')
@@ -104,6 +106,8 @@ def main():
     model.train()
     if args.no_fuse_norm:
         model.fuse_row_norm = False
+    if args.no_fold_embedding:
+        model.fold_embedding = False
     if args.no_swap_wgrad:
         model.swap_big_wgrad = False
     reducer = GradReducer(force=args.rccl_single) if (world > 1 or args.rccl_single) else None

@@ -89,6 +89,18 @@ int vqa_lstm_cell_packed(const float* slabs, int nslab, size_t slab_stride, cons
 /* (gates_out (packed rows x 4H, activated i, f, g, o) and c_out (packed rows x H, fp32), optional and
  *  together: the state saved for backward through time) */
 
+/* The same step with the input projections gathered by token id from a table,
+ *   xg_table[v] = act(embedding[v]) W_ih^T + b_ih + b_hh   (n_table_rows x 4H),
+ * which the caller builds once per weight version when the embedding and W_ih are frozen (the reference freezes
+ * the whole encoder, model.py:42-43): the embedding gather and the input projection of every step collapse into
+ * this gather; row j of step t reads xg_table[tokens[perm[j], t]] (ids outside the table read row 0, the pad
+ * row).  No state is saved for backward through time.              seq2vec.py:42-43, 63-66 */
+int vqa_lstm_cell_packed_table(const float* slabs, int nslab, size_t slab_stride, const void* xg_table, int ld_xg,
+                               int n_table_rows, const int64_t* tokens, float* c, void* h, int ld_h,
+                               const int32_t* lengths, float* q_f32, void* q_t, int ld_q, int B, int H, int t, int L,
+                               const int32_t* perm, const int32_t* active, const int32_t* offsets, void* hs, int ld_hs,
+                               void* q_drop, unsigned drop_seed, float drop_p, int dtype, hipStream_t stream);
+
 /* Backward through LSTM step t on packed sequences (a trainable question encoder; the reference
  * freezes it, model.py:42-43, so this has no counterpart there beyond autograd of seq2vec.py:43):
  * slabs = dG_{t+1} W_hh partial sums (rows running at t+1), dq (B, ld_dq) in original row order is the

@@ -110,3 +110,27 @@ def test_train_steps_update_the_encoder_like_the_oracle():
             continue
         # Adam turns rounding-level gradients into +-lr steps: compare where the oracle's gradient is not noise
         assert rel_err(sd[k], po[k]) <= 5e-4, k
+
+
+@pytest.mark.parametrize('arch', ['lstm', '2-lstm'])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_folded_embedding_table_matches_per_step_projection(arch, dtype):
+    """Frozen encoder: the per-token table of input projections (embedding folded into W_ih) gives the question
+    vector of the gather + per-step projection path bit for bit, for ragged lengths, pad rows and ids outside the table."""
+    from vqa_amd.model import VQAAttnModel
+    kw = dict(emb_size=20, question_out=48, visual_out=72, attention_dim=24, fusion_in=40, fusion_hidden=16)
+    Vq, C, B, L = 37, 9, 29, 11
+    g = torch.Generator().manual_seed(3)
+    tok = torch.randint(1, Vq + 1, (B, L), generator=g)
+    lens = torch.randint(0, L + 1, (B,), generator=g)
+    tok[torch.arange(L)[None, :] >= lens[:, None]] = 0
+    tok[3, 0] = Vq + 5                                    # outside the table: reads the pad row
+    outs = []
+    for fold in (True, False):
+        m = VQAAttnModel(['w'] * Vq, ['a'] * C, None, dtype=dtype, seq2vec_arch=arch, seed=9, **kw).to('cuda').eval()
+        m.fold_embedding = fold
+        q = m.encode_question(tok.cuda()).clone()
+        torch.cuda.synchronize()
+        assert (m._xg_table is not None) == fold
+        outs.append(q)
+    assert torch.equal(outs[0], outs[1])

@@ -166,9 +166,15 @@ def test_question_encoder_against_reference_fixture(golden_dir, dtype):
     for name in ('main', 'rand'):
         ids = torch.from_numpy(z[f'{name}_ids']).cuda()
         B, L = ids.shape
+        m.fold_embedding = True         # per-token table of input projections (frozen encoder): same question vector
+        q_table = m.encode_question(ids).clone()
+        assert m._xg_table is not None
+        assert rel_err(q_table, torch.from_numpy(z[f'{name}_last'])) <= tol
+        m.fold_embedding = False        # gather + per-step projection: the intermediate gather is checked below
         q = m.encode_question(ids)
         ws = m._enc_workspace(B, L, ids.device)
         torch.cuda.synchronize()
+        assert m._xg_table is None and torch.equal(q, q_table)
         assert np.array_equal(ws['len'].cpu().numpy(), z[f'{name}_lengths'].astype(np.int32))
         # packed gather: row offs[t] + j holds the embedding of token t of sorted row j (= original row
         # perm[j]) for the m_t[t] rows still running; bit-exact against the table in the storage dtype

@@ -171,22 +171,48 @@ __global__ void __launch_bounds__(256) k_lstm_cell(const float* __restrict__ sla
                             int B, int H, int t, int L, const int* __restrict__ perm,
                             const int* __restrict__ m_t, const int* __restrict__ offs,
                             T* __restrict__ hs, int ld_hs, T* __restrict__ gates_out, float* __restrict__ cs_out,
-                            T* __restrict__ q_drop, unsigned seed, unsigned thr, float dscale) {
+                            T* __restrict__ q_drop, unsigned seed, unsigned thr, float dscale,
+                            const int64_t* __restrict__ tok = nullptr, int n_table = 0) {
     // packed mode (perm != null): state rows are in sorted order, only the first m_t[t] are live, their
-    // input-projection rows start at row offs[t] of xg and q goes to the original row perm[b]
+    // input-projection rows start at row offs[t] of xg and q goes to the original row perm[b].
+    // table mode (tok != null, packed): xg is a table of input projections per token id (a frozen embedding
+    // folded into the frozen W_ih) and the row of sorted row b is xg[tok[perm[b], t]].
     const int H4 = H >> 2;
     const int rows = perm ? m_t[t] : B;
     const long xrow0 = perm ? offs[t] : 0;
     const long total = (long)rows * H4;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int b = (int)(i / H4), j = (int)(i % H4) * 4;
+        const int ob = perm ? perm[b] : b;
+        long xrow = xrow0 + b;
+        if (tok) {
+            int64_t id = tok[(size_t)ob * L + t];
+            if (id < 0 || id >= n_table) id = 0;            // as the gather: ids outside the table read the pad row
+            xrow = (long)id;
+        }
         f32x4 g[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) g[k] = Vec4<T>::load(xg + (size_t)(xrow0 + b) * ld_xg + k * H + j);
-        for (int s = 0; s < nslab; ++s) {
-            const float* sl = slabs + s * slab_stride + (size_t)b * 4 * H + j;
+        for (int k = 0; k < 4; ++k) g[k] = Vec4<T>::load(xg + (size_t)xrow * ld_xg + k * H + j);
+        // the loads of the first four slabs are issued together (a loop with a run-time trip count waits for each)
+        if (nslab > 0) {
+            f32x4 sv[4][4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) g[k] += Vec4<float>::load(sl + k * H);
+            for (int s = 0; s < 4; ++s) {
+                const float* sl = slabs + (size_t)min(s, nslab - 1) * slab_stride + (size_t)b * 4 * H + j;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) sv[s][k] = Vec4<float>::load(sl + k * H);
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                if (s < nslab) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) g[k] += sv[s][k];
+                }
+            for (int s = 4; s < nslab; ++s) {
+                const float* sl = slabs + s * slab_stride + (size_t)b * 4 * H + j;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) g[k] += Vec4<float>::load(sl + k * H);
+            }
         }
         f32x4 cprev = f32x4{0.f, 0.f, 0.f, 0.f};
         if (t != 0) cprev = Vec4<float>::load(c + (size_t)b * H + j);
@@ -207,7 +233,6 @@ __global__ void __launch_bounds__(256) k_lstm_cell(const float* __restrict__ sla
         Vec4<float>::store(c + (size_t)b * H + j, cn);
         Vec4<T>::store(h + (size_t)b * ld_h + j, hn);
         if (hs) Vec4<T>::store(hs + (size_t)(xrow0 + b) * ld_hs + j, hn);     // every step's output, packed rows
-        const int ob = perm ? perm[b] : b;
         int last = len[ob] - 1;
         if (last < 0) last += L;               // all-pad row: negative index -> last step
         if (last == t) {
@@ -977,6 +1002,27 @@ int vqa_lstm_cell_packed(const float* slabs, int nslab, size_t slab_stride, cons
         slabs, nslab, slab_stride, (const T*)xg, ld_xg, c, (T*)h, ld_h, lengths, q_f32, (T*)q_t, ld_q, B, H, t, L,
         perm, active, offsets, (T*)hs, ld_hs, (T*)gates_out, c_out, (T*)q_drop, drop_seed, thr, dsc)));
     return vqa_check_launch("vqa_lstm_cell_packed");
+}
+
+int vqa_lstm_cell_packed_table(const float* slabs, int nslab, size_t slab_stride, const void* xg_table, int ld_xg,
+                               int n_table_rows, const int64_t* tokens, float* c, void* h, int ld_h,
+                               const int32_t* lengths, float* q_f32, void* q_t, int ld_q, int B, int H, int t, int L,
+                               const int32_t* perm, const int32_t* active, const int32_t* offsets, void* hs, int ld_hs,
+                               void* q_drop, unsigned drop_seed, float drop_p, int dtype, hipStream_t stream) {
+    VQA_REQUIRE(xg_table && tokens && n_table_rows > 0 && c && h && lengths && q_f32 && q_t && perm && active && offsets &&
+                (nslab == 0 || slabs), "vqa_lstm_cell_packed_table: null pointer");
+    VQA_REQUIRE(B >= 0 && H > 0 && t >= 0 && t < L && ld_xg >= 4 * H && ld_h >= H && ld_q >= H, "vqa_lstm_cell_packed_table: bad sizes");
+    VQA_REQUIRE(H % 4 == 0 && ld_xg % 4 == 0 && ld_h % 4 == 0 && ld_q % 4 == 0 && (slab_stride % 4 == 0 || nslab <= 1),
+                "vqa_lstm_cell_packed_table: H and leading dimensions must be multiples of 4");
+    VQA_REQUIRE(!hs || (ld_hs >= H && ld_hs % 4 == 0), "vqa_lstm_cell_packed_table: bad ld_hs");
+    VQA_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "vqa_lstm_cell_packed_table: drop_p must be in [0, 1)");
+    const unsigned thr = drop_threshold(drop_p);
+    const float dsc = 1.0f / (1.0f - drop_p);
+    if (B == 0) return 0;
+    DISPATCH_T(dtype, (k_lstm_cell<T><<<grid_for((long)B * (H / 4), 256), 256, 0, stream>>>(
+        slabs, nslab, slab_stride, (const T*)xg_table, ld_xg, c, (T*)h, ld_h, lengths, q_f32, (T*)q_t, ld_q, B, H, t, L,
+        perm, active, offsets, (T*)hs, ld_hs, (T*)nullptr, nullptr, (T*)q_drop, drop_seed, thr, dsc, tokens, n_table_rows)));
+    return vqa_check_launch("vqa_lstm_cell_packed_table");
 }
 
 int vqa_lstm_cell(const float* slabs, int nslab, size_t slab_stride, const void* xg_t, int ld_xg, float* c,

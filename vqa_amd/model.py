@@ -178,6 +178,7 @@ class _VQAHeadModel(nn.Module):
         self._frozen_key = None
         self._shadow_fresh = False
         self._ctx = None
+        self.fold_embedding = True    # frozen encoder: embedding x first input projection tabulated per token id
         self.grad_ready_hook = None   # callable(bucket_index) fired as gradient buckets complete
         self.kernel_events = None     # set to {} to collect per-kernel HIP event pairs
         self.kernel_event_stride = 1  # time every n-th launch only (an event pair costs the stream ~10 us of gaps)
@@ -290,7 +291,7 @@ class _VQAHeadModel(nn.Module):
             ps += [rnn.weight_ih_l0, rnn.weight_hh_l0, rnn.bias_ih_l0, rnn.bias_hh_l0]
         if self.Ec:
             ps.append(self.caption_embedding.weight)
-        key = tuple((p.data_ptr(), p._version) for p in ps) + (str(device),)
+        key = tuple((p.data_ptr(), p._version) for p in ps) + (str(device), self.fold_embedding, self.train_encoder)
         if key == self._frozen_key:
             return
         tdt = self.compute_dtype
@@ -309,6 +310,26 @@ class _VQAHeadModel(nn.Module):
                                      (rnn.bias_ih_l0.detach().float() + rnn.bias_hh_l0.detach().float()).to(device).contiguous()))
         if self.Ec:
             self._cap_t = cast_pad(ps[-1], self.Ec)
+        # Frozen encoder: embedding followed by the first layer's input projection is one fixed map per token id, so
+        # it is tabulated here, once per weight version: xg_table[v] = act(emb[v]) W_ih^T + b_ih + b_hh, computed by
+        # the same GEMM kernel on the same rows as the per-step projection it replaces (bit-identical values).
+        self._xg_table = None
+        V1, H4 = self._emb_t.shape[0], 4 * self.seq2vec.layers[0].hidden_size
+        if self.fold_embedding and not self.train_encoder and V1 * H4 * self._emb_t.element_size() <= (1 << 30):
+            wih, _, bias = self._enc_layers[0]
+            Ep = _pad8(self.E)
+            emb = self._emb_t
+            if self.seq2vec.arch == '2-lstm':             # TwoLSTM feeds tanh(embedding) (seq2vec.py:63-64)
+                emb = torch.empty_like(self._emb_t)
+                ident = torch.arange(V1, device=device, dtype=torch.int64).view(V1, 1).contiguous()
+                one = torch.zeros(1, dtype=torch.int32, device=device)
+                offs = torch.tensor([0, V1], dtype=torch.int32, device=device)
+                call('vqa_embedding_gather_packed', ptr(ident), ptr(self._emb_t), ptr(emb), V1, 1, Ep, Ep, Ep, V1,
+                     ptr(torch.arange(V1, device=device, dtype=torch.int32)), ptr(offs), 1, None, self.dt)
+            table = torch.empty((V1, H4), dtype=tdt, device=device)
+            call('vqa_gemm_fused', ptr(emb), Ep, 1, ptr(wih), Ep, 1, ptr(table), H4, V1, H4, Ep, ptr(bias), None, 0,
+                 self.dt, self.dt, self.gemm_engine)
+            self._xg_table = table
         self._frozen_key = key
 
     # ------------------------------------------------------------------ workspace
@@ -522,8 +543,10 @@ class _VQAHeadModel(nn.Module):
         # packed sequences: rows sorted by length, so the rows still running at step t are the first
         # m_t[t] and their input projections are rows offs[t].. of xg; padding steps cost nothing
         call('vqa_sequence_pack', ptr(tokens), B, L, ptr(ws['len']), ptr(ws['perm']), ptr(ws['m_t']), ptr(ws['offs']))
-        call('vqa_embedding_gather_packed', ptr(tokens), ptr(self._emb_t), ptr(ws['x_emb']), B, L, Ep, Ep, Ep,
-             self._emb_t.shape[0], ptr(ws['perm']), ptr(ws['offs']), 1 if two else 0, ptr(ws.get('ptok')), dt)
+        table = self._xg_table                  # frozen encoder: gather + first input projection come from one table
+        if table is None:
+            call('vqa_embedding_gather_packed', ptr(tokens), ptr(self._emb_t), ptr(ws['x_emb']), B, L, Ep, Ep, Ep,
+                 self._emb_t.shape[0], ptr(ws['perm']), ptr(ws['offs']), 1 if two else 0, ptr(ws.get('ptok')), dt)
         total_rows = ws['offs'].data_ptr() + 4 * L
         x, kin = ws['x_emb'], Ep
         esz = ws['qT'].element_size()
@@ -533,8 +556,10 @@ class _VQAHeadModel(nn.Module):
             save = self.train_encoder and self._bptt
             hs = ws[f'hs{li}'] if save else (None if last_layer else ws['hs'])
             gates, cs = (ws[f'gates{li}'], ws[f'cs{li}']) if save else (None, None)
-            call('vqa_gemm_fused_rows', ptr(x), kin, 1, ptr(wih), kin, 1, ptr(ws['xg']), 4 * Hh,
-                 L * B, 4 * Hh, kin, ptr(bias), None, 0, dt, dt, self.gemm_engine, total_rows)
+            from_table = li == 0 and table is not None
+            if not from_table:
+                call('vqa_gemm_fused_rows', ptr(x), kin, 1, ptr(wih), kin, 1, ptr(ws['xg']), 4 * Hh,
+                     L * B, 4 * Hh, kin, ptr(bias), None, 0, dt, dt, self.gemm_engine, total_rows)
             q32 = ws['q32'].data_ptr() + 4 * li * Hh            # this layer's columns of q
             qT = ws['qT'].data_ptr() + esz * li * Hh
             for t in range(L):
@@ -543,6 +568,13 @@ class _VQAHeadModel(nn.Module):
                 else:
                     slab, sk, stride = self._gemm_slabs(ws['h'], Hh, 1, whh, Hh, 1, B, 4 * Hh, Hh,
                                                         active_rows=ws['m_t'].data_ptr() + 4 * t)
+                if from_table:
+                    call('vqa_lstm_cell_packed_table', ptr(slab), sk, stride, ptr(table), 4 * Hh, table.shape[0], ptr(tokens),
+                         ptr(ws['c']), ptr(ws['h']), Hh, ptr(ws['len']), q32, qT, Hq, B, Hh, t, L, ptr(ws['perm']),
+                         ptr(ws['m_t']), ptr(ws['offs']), ptr(hs), Hh,
+                         ptr(q_drop[0]) if fuse_drop else None, q_drop[1] if fuse_drop else 0,
+                         q_drop[2] if fuse_drop else 0.0, dt)
+                    continue
                 call('vqa_lstm_cell_packed', ptr(slab), sk, stride, ptr(ws['xg']), 4 * Hh, ptr(ws['c']), ptr(ws['h']), Hh,
                      ptr(ws['len']), q32, qT, Hq, B, Hh, t, L, ptr(ws['perm']), ptr(ws['m_t']),
                      ptr(ws['offs']), ptr(hs), Hh, ptr(gates), ptr(cs),
