@@ -161,7 +161,10 @@ def main():
             'config': {'workload': f'VQA-v2-shaped synthetic, {R} regions x {Dv} bf16 precomputed feats, '
                                    f'{L}-token questions, {C} answers, batch {B}/GPU, {args.hops} attention hop(s), '
                                    f'fwd+CE+bwd+all-reduce+Adam, dropout on',
-                       'global_batch': world * B, 'parallelism': f'dp{world}'},
+                       'global_batch': world * B, 'parallelism': f'dp{world}',
+                       'question_encoder': 'frozen, as the reference trains it; embedding x first LSTM input projection '
+                                           + ('tabulated per token id when the weights are loaded' if model.fold_embedding
+                                              else 'computed every step')},
             'roofline': {'bound': 'hbm', 'kernel': 'k_attn_fwd_online (fused attention forward)', 'achieved': achieved,
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'avg_launch_ms': k6_ms, 'timed_launches': len(ev),
