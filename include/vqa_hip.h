@@ -296,6 +296,10 @@ int vqa_slab_sum_transpose(const float* slabs, int nslab, size_t slab_stride, in
 #define VQA_COLSUM_MAX 8
 typedef struct VqaColsumDesc { const void* X; int ld; int M; int N; int dtype; float scale; float* out; float* out2; } VqaColsumDesc;
 int vqa_colsum_multi(const VqaColsumDesc* descs, int n, hipStream_t stream);
+/* vqa_gemm_slabs_group with a batch of column sums (vqa_colsum_multi's problems: the bias gradients that go with the
+ * weight gradients) appended as extra workgroups. */
+int vqa_gemm_slabs_group_colsum(const VqaGemmDesc* descs, int n, int a_kmajor, int b_kmajor, int dtype,
+                                const VqaColsumDesc* colsums, int n_colsums, hipStream_t stream);
 /* the same over the first *rows rows (a device-side count) */
 int vqa_colsum_rows(const void* X, int ld, float* out, const int32_t* rows, int N, int dtype, hipStream_t stream);
 /* dst[m,0:N] = (dtype) src[m,0:N]; dst[m,N:ld_dst] = 0 */

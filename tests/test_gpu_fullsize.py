@@ -128,7 +128,7 @@ def test_cfg4_caption_stream_full_width():
 def test_cfg2_fast_paths_agree_with_plain_paths(full_model):
     """Config 2, one train-mode forward + backward with every fused fast path on (row norms inside the projection
     GEMM, the big weight gradient in the swapped orientation, grouped small products, partial sums reduced in the
-    consumers' prologues) against the same step with the separate-kernel paths: same loss and gradients to bf16
+    consumers' prologues, the per-token table of input projections) against the same step with the separate-kernel paths: same loss and gradients to bf16
     rounding of the intermediate activations (the fused norm sums its squares in a different order)."""
     from vqa_amd.model import VQAAttnModel
     m, p = full_model
@@ -142,9 +142,17 @@ def test_cfg2_fast_paths_agree_with_plain_paths(full_model):
         mm.fuse_row_norm = fast
         mm.swap_big_wgrad = fast
         mm._dpool_from_slabs = fast
+        mm.fold_embedding = fast
         if not fast:
             mm._launch_early = lambda ws, B: ws.__setitem__('early', {})
-            mm._wgrad_grouped = lambda items: [mm._wgrad(*it, defer=True) for it in items]
+
+            def plain_wgrads(items, colsums=None, mm=mm):
+                from vqa_amd import _lib
+                if colsums:
+                    _lib.colsum_multi(colsums)
+                for it in items:
+                    mm._wgrad(*it, defer=True)
+            mm._wgrad_grouped = plain_wgrads
         logits = mm(feats, tok)
         loss = torch.nn.functional.cross_entropy(logits.float(), ans)
         loss.backward()

@@ -157,3 +157,23 @@ def test_grouped_small_products(akm, bkm):
             assert float((grouped.double().sum(0) - ref).abs().max() / ref.abs().max()) <= 2e-5
     with pytest.raises(_lib.VqaHipError):
         _lib.gemm_slabs_group(problems + problems[:1], akm, bkm, BF16)
+
+
+def test_grouped_products_with_column_sums_in_one_launch():
+    from vqa_amd import _lib
+    M, N, K = 300, 200, 256
+    As, lda, Bs, ldb, ref = make(M, N, K, 0, 0, torch.bfloat16, 5)
+    slab = torch.full((1, M, N), float('nan'), device='cuda')
+    g = torch.Generator(device='cuda').manual_seed(1)
+    X1 = torch.randn(77, 130, device='cuda', generator=g)
+    X2 = torch.randn(256, 40, device='cuda', generator=g).to(torch.bfloat16)
+    o1 = torch.zeros(130, device='cuda'); o1b = torch.zeros(130, device='cuda'); o2 = torch.zeros(40, device='cuda')
+    _lib.gemm_slabs_group([(ptr(As), lda, ptr(Bs), ldb, ptr(slab), M * N, N, M, N, K, 1)], 0, 0, BF16,
+                          colsums=[(X1, 130, 77, 130, F32, o1, o1b, 0.5), (X2, 40, 256, 40, BF16, o2, None)])
+    torch.cuda.synchronize()
+    assert float((slab[0].double() - ref).abs().max() / ref.abs().max()) <= 2e-5
+    r1 = torch.zeros_like(o1); r2 = torch.zeros_like(o2)
+    _lib.colsum_multi([(X1, 130, 77, 130, F32, r1, None, 0.5), (X2, 40, 256, 40, BF16, r2, None)])
+    torch.cuda.synchronize()
+    assert torch.equal(o1, r1) and torch.equal(o1b, r1) and torch.equal(o2, r2)
+    assert float((o1.double() - 0.5 * X1.double().sum(0)).abs().max()) <= 1e-4

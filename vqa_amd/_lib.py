@@ -52,6 +52,7 @@ _SIGNATURES = {
     'vqa_gemm_slabs': [_p, _i, _i, _p, _i, _i, _p, _z, _i, _i, _i, _i, _i, _i, _i, _p],
     'vqa_gemm_slabs_rows': [_p, _i, _i, _p, _i, _i, _p, _z, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p],
     'vqa_gemm_slabs_group': [_p, _i, _i, _i, _i, _p],
+    'vqa_gemm_slabs_group_colsum': [_p, _i, _i, _i, _i, _p, _i, _p],
     'vqa_slab_sum_transpose': [_p, _i, _z, _i, _i, _p, _i, _p],
     'vqa_fusion_fwd_slabs': [_p, _i, _z, _p, _p, _i, _z, _p, _p, _p, _p, _i, _i, _i, _u, _f, _i, _p],
     'vqa_epilogue_fusion': [_p, _i, _z, _i, _i, _p, _p, _p, _p, _i, _u, _f, _i, _p],
@@ -139,12 +140,7 @@ class ColsumDesc(C.Structure):
 
 def colsum_multi(problems):
     """problems: iterable of (X, ld, M, N, dtype, out, out2-or-None[, scale]) with tensors for X / out / out2."""
-    arr = (ColsumDesc * len(problems))()
-    for d, pr in zip(arr, problems):
-        X, ld, M, N, dt, out, out2 = pr[:7]
-        d.X, d.ld, d.M, d.N, d.dtype, d.out, d.out2 = ptr(X), ld, M, N, dt, ptr(out), ptr(out2)
-        d.scale = pr[7] if len(pr) > 7 else 1.0
-    return call('vqa_colsum_multi', arr, len(problems))
+    return call('vqa_colsum_multi', _colsum_array(problems), len(problems))
 
 
 class SlabSumDesc(C.Structure):
@@ -168,12 +164,24 @@ class GemmDesc(C.Structure):
                 ('M', C.c_int), ('N', C.c_int), ('K', C.c_int), ('splitk', C.c_int)]
 
 
-def gemm_slabs_group(problems, akm: int, bkm: int, dtype: int):
-    """problems: iterable of (A address, lda, B address, ldb, slab address, slab_stride, ld_slab, M, N, K, splitk)."""
+def _colsum_array(problems):
+    arr = (ColsumDesc * len(problems))()
+    for d, pr in zip(arr, problems):
+        X, ld, M, N, dt, out, out2 = pr[:7]
+        d.X, d.ld, d.M, d.N, d.dtype, d.out, d.out2 = ptr(X), ld, M, N, dt, ptr(out), ptr(out2)
+        d.scale = pr[7] if len(pr) > 7 else 1.0
+    return arr
+
+
+def gemm_slabs_group(problems, akm: int, bkm: int, dtype: int, colsums=None):
+    """problems: iterable of (A address, lda, B address, ldb, slab address, slab_stride, ld_slab, M, N, K, splitk);
+    colsums: optional problems of colsum_multi that ride in the same launch."""
     arr = (GemmDesc * len(problems))()
     for d, (A, lda, B, ldb, slabs, stride, ld_slab, M, N, K, sk) in zip(arr, problems):
         d.A, d.lda, d.B, d.ldb, d.slabs, d.slab_stride, d.ld_slab = A, lda, B, ldb, slabs, stride, ld_slab
         d.M, d.N, d.K, d.splitk = M, N, K, sk
+    if colsums:
+        return call('vqa_gemm_slabs_group_colsum', arr, len(problems), akm, bkm, dtype, _colsum_array(colsums), len(colsums))
     return call('vqa_gemm_slabs_group', arr, len(problems), akm, bkm, dtype)
 
 

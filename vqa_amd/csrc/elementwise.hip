@@ -4,6 +4,7 @@
 // per-lane accesses and computes in fp32.  Storage type T is float or raw bf16.
 #include "common.h"
 #include "vqa_hip.h"
+#include "colsum.h"
 
 template <typename T> struct Act {
     static __device__ __forceinline__ float tanh_(float x) { return fast_tanh(x); }
@@ -593,45 +594,10 @@ __global__ void __launch_bounds__(256) k_slab_sum_transpose4(const float* __rest
     }
 }
 
-// several column sums in one launch: problem i sums the M_i rows of X_i (fp32 or bf16) into out_i (and out2_i)
-struct ColsumBatch { VqaColsumDesc d[VQA_COLSUM_MAX]; int first_block[VQA_COLSUM_MAX + 1]; int n; };
-
+// several column sums in one launch (colsum.h: the work of one block is shared with the grouped GEMM launch)
 __global__ void __launch_bounds__(256) k_colsum_multi(ColsumBatch batch) {
     __shared__ float part[8][33];
-    int pi = 0;
-    while (pi + 1 < batch.n && (int)blockIdx.x >= batch.first_block[pi + 1]) ++pi;
-    const VqaColsumDesc d = batch.d[pi];
-    const int cx = threadIdx.x & 31, rg = threadIdx.x >> 5;
-    const int n = ((int)blockIdx.x - batch.first_block[pi]) * 32 + cx;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    if (n < d.N) {
-        int m = rg;
-        if (d.dtype == VQA_BF16) {
-            const bf16_t* X = (const bf16_t*)d.X;
-            for (; m + 24 < d.M; m += 32) {
-                s0 += bf16_to_f32(X[(size_t)m * d.ld + n]); s1 += bf16_to_f32(X[(size_t)(m + 8) * d.ld + n]);
-                s2 += bf16_to_f32(X[(size_t)(m + 16) * d.ld + n]); s3 += bf16_to_f32(X[(size_t)(m + 24) * d.ld + n]);
-            }
-            for (; m < d.M; m += 8) s0 += bf16_to_f32(X[(size_t)m * d.ld + n]);
-        } else {
-            const float* X = (const float*)d.X;
-            for (; m + 24 < d.M; m += 32) {
-                s0 += X[(size_t)m * d.ld + n]; s1 += X[(size_t)(m + 8) * d.ld + n];
-                s2 += X[(size_t)(m + 16) * d.ld + n]; s3 += X[(size_t)(m + 24) * d.ld + n];
-            }
-            for (; m < d.M; m += 8) s0 += X[(size_t)m * d.ld + n];
-        }
-    }
-    part[rg][cx] = (s0 + s1) + (s2 + s3);
-    __syncthreads();
-    if (rg == 0 && n < d.N) {
-        float s = 0.f;
-#pragma unroll
-        for (int g = 0; g < 8; ++g) s += part[g][cx];
-        s *= d.scale;
-        d.out[n] = s;
-        if (d.out2) d.out2[n] = s;
-    }
+    colsum_block(batch, (int)blockIdx.x, part);
 }
 
 // cast fp32 -> T with row padding: dst[m, 0:N] = src[m, 0:N], dst[m, N:ld_dst] = 0
@@ -1203,19 +1169,9 @@ int vqa_slab_sum_transpose(const float* slabs, int nslab, size_t slab_stride, in
 }
 
 int vqa_colsum_multi(const VqaColsumDesc* descs, int n, hipStream_t stream) {
-    VQA_REQUIRE(descs && n >= 1 && n <= VQA_COLSUM_MAX, "vqa_colsum_multi: 1..8 problems");
     ColsumBatch batch;
-    batch.n = n;
     int blocks = 0;
-    for (int i = 0; i < n; ++i) {
-        const VqaColsumDesc& d = descs[i];
-        VQA_REQUIRE(d.X && d.out && d.M >= 0 && d.N > 0 && d.ld >= d.N && (d.dtype == VQA_F32 || d.dtype == VQA_BF16),
-                    "vqa_colsum_multi: bad problem");
-        batch.d[i] = d;
-        batch.first_block[i] = blocks;
-        blocks += (d.N + 31) / 32;
-    }
-    batch.first_block[n] = blocks;
+    if (int rc = colsum_fill(descs, n, batch, blocks)) return rc;
     k_colsum_multi<<<blocks, 256, 0, stream>>>(batch);
     return vqa_check_launch("vqa_colsum_multi");
 }

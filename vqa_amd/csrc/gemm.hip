@@ -18,6 +18,7 @@
 // fp32 path (the 1e-5 parity mode): a plain LDS-tiled VALU kernel, any strides.
 #include "common.h"
 #include "vqa_hip.h"
+#include "colsum.h"
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
@@ -394,6 +395,23 @@ struct GemmGroup {
     int first_block[VQA_GEMM_GROUP_MAX + 1];
     int n;
 };
+
+// The same launch with the blocks of a batch of column sums (bias gradients) appended after the GEMM blocks.
+template <bool AKM, bool BKM>
+__global__ void __launch_bounds__(256) k_gemm_bf16_group_colsum(GemmGroup g, ColsumBatch cs) {
+    const int ngemm = g.first_block[g.n];
+    if ((int)blockIdx.x >= ngemm) {
+        __shared__ float part[8][33];
+        colsum_block(cs, (int)blockIdx.x - ngemm, part);
+        return;
+    }
+    int p = 0;
+    while (p + 1 < g.n && (int)blockIdx.x >= g.first_block[p + 1]) ++p;
+    Epi epi{g.out[p], g.ldo[p], 0, g.split_stride[p], nullptr, nullptr, 0, nullptr, nullptr, nullptr};
+    gemm_bf16_workgroup<64, 64, AKM, BKM>(g.A[p], g.lda[p], g.B[p], g.ldb[p], g.M[p], g.N[p], g.K[p], g.tiles_m[p],
+                                          g.tiles_n[p], g.kps[p], epi, (int)blockIdx.x - g.first_block[p],
+                                          g.first_block[p + 1] - g.first_block[p]);
+}
 
 template <bool AKM, bool BKM>
 __global__ void __launch_bounds__(256) k_gemm_bf16_group(GemmGroup g) {
@@ -954,7 +972,21 @@ int vqa_gemm_slabs_rows(const void* A, int lda, int a_kmajor, const void* B, int
     return vqa_check_launch("vqa_gemm_slabs");
 }
 
+static int gemm_group_impl(const VqaGemmDesc* descs, int n, int a_kmajor, int b_kmajor, int dtype,
+                           const VqaColsumDesc* cdescs, int nc, hipStream_t stream);
+
 int vqa_gemm_slabs_group(const VqaGemmDesc* descs, int n, int a_kmajor, int b_kmajor, int dtype, hipStream_t stream) {
+    return gemm_group_impl(descs, n, a_kmajor, b_kmajor, dtype, nullptr, 0, stream);
+}
+
+int vqa_gemm_slabs_group_colsum(const VqaGemmDesc* descs, int n, int a_kmajor, int b_kmajor, int dtype,
+                                const VqaColsumDesc* colsums, int n_colsums, hipStream_t stream) {
+    VQA_REQUIRE(colsums && n_colsums >= 1, "vqa_gemm_slabs_group_colsum: no column sums");
+    return gemm_group_impl(descs, n, a_kmajor, b_kmajor, dtype, colsums, n_colsums, stream);
+}
+
+static int gemm_group_impl(const VqaGemmDesc* descs, int n, int a_kmajor, int b_kmajor, int dtype,
+                           const VqaColsumDesc* cdescs, int nc, hipStream_t stream) {
     VQA_REQUIRE(descs && n >= 1 && n <= VQA_GEMM_GROUP_MAX, "vqa_gemm_slabs_group: 1..4 products");
     bool mfma = dtype == VQA_BF16;
     for (int i = 0; i < n; ++i) {
@@ -969,7 +1001,7 @@ int vqa_gemm_slabs_group(const VqaGemmDesc* descs, int n, int a_kmajor, int b_km
             if (int rc = vqa_gemm_slabs(d.A, d.lda, a_kmajor, d.B, d.ldb, b_kmajor, d.slabs, d.slab_stride, d.ld_slab, d.M, d.N,
                                         d.K, d.splitk, dtype, 0, stream)) return rc;
         }
-        return 0;
+        return cdescs ? vqa_colsum_multi(cdescs, nc, stream) : 0;
     }
     GemmGroup g;
     g.n = n;
@@ -984,6 +1016,17 @@ int vqa_gemm_slabs_group(const VqaGemmDesc* descs, int n, int a_kmajor, int b_km
         blocks += g.tiles_m[i] * g.tiles_n[i] * d.splitk;
     }
     g.first_block[n] = blocks;
+    if (cdescs) {
+        ColsumBatch cs;
+        int cblocks = 0;
+        if (int rc = colsum_fill(cdescs, nc, cs, cblocks)) return rc;
+        const int total = blocks + cblocks;
+        if (a_kmajor && b_kmajor) k_gemm_bf16_group_colsum<true, true><<<total, 256, 0, stream>>>(g, cs);
+        else if (a_kmajor && !b_kmajor) k_gemm_bf16_group_colsum<true, false><<<total, 256, 0, stream>>>(g, cs);
+        else if (!a_kmajor && b_kmajor) k_gemm_bf16_group_colsum<false, true><<<total, 256, 0, stream>>>(g, cs);
+        else k_gemm_bf16_group_colsum<false, false><<<total, 256, 0, stream>>>(g, cs);
+        return vqa_check_launch("vqa_gemm_slabs_group_colsum");
+    }
     if (a_kmajor && b_kmajor) k_gemm_bf16_group<true, true><<<blocks, 256, 0, stream>>>(g);
     else if (a_kmajor && !b_kmajor) k_gemm_bf16_group<true, false><<<blocks, 256, 0, stream>>>(g);
     else if (!a_kmajor && b_kmajor) k_gemm_bf16_group<false, true><<<blocks, 256, 0, stream>>>(g);

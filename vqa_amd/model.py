@@ -409,11 +409,13 @@ class _VQAHeadModel(nn.Module):
         call('vqa_epilogue', ptr(slab), sk, stride, M, N, None, None, None, 0, 0, ptr(self._g(wname)), N,
              None, 0, _lib.F32, 0, 0.0)
 
-    def _wgrad_grouped(self, items):
+    def _wgrad_grouped(self, items, colsums=None):
         """Several weight gradients (dy, ld_dy, x, ldx, wname, M, N, K), each grad(W)[M,N] = dy^T x, as one launch
         when their contraction is short; a product with one K range is written straight into the gradient buffer,
         the others leave partial sums for _flush_wgrads()."""
         if self.dt != _lib.BF16 or any(K > 512 for *_, K in items) or len(items) > 4:
+            if colsums:
+                _lib.colsum_multi(colsums)
             for dy, ld_dy, x, ldx, wname, M, N, K in items:
                 self._wgrad(dy, ld_dy, x, ldx, wname, M, N, K, defer=True)
             return
@@ -426,7 +428,7 @@ class _VQAHeadModel(nn.Module):
                 addr = self._arena(sk * M * N, dy.device)
                 self._wgrad_pending.append((addr, sk, M * N, M * N, self._g(wname)))
             problems.append((ptr(dy), ld_dy, ptr(x), ldx, addr, M * N, N, M, N, K, sk))
-        _lib.gemm_slabs_group(problems, 0, 0, self.dt)
+        _lib.gemm_slabs_group(problems, 0, 0, self.dt, colsums)       # (bias gradients ride in the same launch)
 
     def _q_side_products(self, ws):
         """Forward products whose input is ready as soon as the question is encoded: (key, x, ldx, weight name, N, K).
@@ -696,14 +698,15 @@ class _VQAHeadModel(nn.Module):
         # the four bias gradients of the head (and the mean of the per-row losses) in one launch
         extra = [(ws['loss_rows'], 1, B, 1, _lib.F32, ws['loss'], None, 1.0 / B)] if self._loss_pending else []
         self._loss_pending = False
-        _lib.colsum_multi(extra + [(ws['dlogits'], Cp, B, C, dt, g('linear_classif2.bias'), None),
-                           (ws['dz1'], Hf, B, Hf, dt, g('linear_classif1.bias'), None),
-                           (ws['dzv'], F, B, F, dt, g('linear_v.bias'), None),
-                           (ws['dzq'], F, B, F, dt, g('linear_q.bias'), None)])
+        head_bias = extra + [(ws['dlogits'], Cp, B, C, dt, g('linear_classif2.bias'), None),
+                             (ws['dz1'], Hf, B, Hf, dt, g('linear_classif1.bias'), None),
+                             (ws['dzv'], F, B, F, dt, g('linear_v.bias'), None),
+                             (ws['dzq'], F, B, F, dt, g('linear_q.bias'), None)]
         self._wgrad_grouped([(ws['dlogits'], Cp, ws['h1d'], Hf, 'linear_classif2.weight', C, Hf, B),
                              (ws['dz1'], Hf, ws['x'], F + Ec, 'linear_classif1.weight', Hf, F + Ec, B),
                              (ws['dzv'], F, ws['pooled_d'], Dv, 'linear_v.weight', F, Dv, B),
-                             (ws['dzq'], F, ws['q_d'], H, 'linear_q.weight', F, H, B)])   # the head's four weight gradients: one launch
+                             (ws['dzq'], F, ws['q_d'], H, 'linear_q.weight', F, H, B)],
+                            colsums=head_bias)                 # the head's four weight and bias gradients: one launch
         self._flush_wgrads()                      # (those with split K: partial sums reduced in one launch)
         self._bucket_done('linear_q.bias')
         slab, sk, st = self._gemm_slabs(ws['dzv'], F, 1, self._w('linear_v.weight'), Dv, 0, B, Dv, F)
@@ -1057,10 +1060,11 @@ class VQAAttnModel(_VQAHeadModel):
                      ptr(ws['dP']), A, ptr(ws['dqa32']), ptr(ws['dqaT']), A, ptr(ws['dwa_part']), ptr(ws['dc_part']),
                      B, R, A, Dv, dt)
             # the hop's small gradients in one launch: w_a, its offset c, and the two biases that share d(P + qa)
-            _lib.colsum_multi([(ws['dwa_part'], A, B, A, _lib.F32, g(pre + 'linear_a.weight'), None),
-                               (ws['dc_part'], 1, B, 1, _lib.F32, g(pre + 'linear_a.bias'), None),
-                               (ws['dqa32'], A, B, A, _lib.F32, g(pre + 'linear_qa.bias'), g(pre + 'linear_va.bias'))])
-            self._wgrad(ws['dqaT'], A, uT, H, pre + 'linear_qa.weight', A, H, B)
+            self._wgrad_grouped([(ws['dqaT'], A, uT, H, pre + 'linear_qa.weight', A, H, B)],
+                                colsums=[(ws['dwa_part'], A, B, A, _lib.F32, g(pre + 'linear_a.weight'), None),
+                                         (ws['dc_part'], 1, B, 1, _lib.F32, g(pre + 'linear_a.bias'), None),
+                                         (ws['dqa32'], A, B, A, _lib.F32, g(pre + 'linear_qa.bias'), g(pre + 'linear_va.bias'))])
+            self._flush_wgrads()
             if k > 0:
                 ppre = f'attention.{k - 1}.'
                 slab, sk, st = self._gemm_slabs(ws['dqaT'], A, 1, self._w(pre + 'linear_qa.weight'), H, 0, B, H, A)
