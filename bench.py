@@ -81,6 +81,7 @@ def main():
     ap.add_argument('--no-fuse-norm', action='store_true', help='A/B: separate row-norm pass before the image projection')
     ap.add_argument('--no-fold-embedding', action='store_true',
                     help='A/B: gather embeddings and run the LSTM input projection every step instead of the per-token table')
+    ap.add_argument('--no-fold-first-step', action='store_true', help='A/B: run the recurrent product of step 1 as a GEMM')
     ap.add_argument('--no-swap-wgrad', action='store_true', help='A/B: dW_va in the nn.Linear orientation')
     ap.add_argument('--rccl-single', action='store_true',
                     help='N=1 only: run the bucketed all-reduce path over a one-rank RCCL group (its cost without peers)')
@@ -108,6 +109,8 @@ def main():
         model.fuse_row_norm = False
     if args.no_fold_embedding:
         model.fold_embedding = False
+    if args.no_fold_first_step:
+        model.fold_first_step = False
     if args.no_swap_wgrad:
         model.swap_big_wgrad = False
     reducer = GradReducer(force=args.rccl_single) if (world > 1 or args.rccl_single) else None
@@ -164,7 +167,9 @@ def main():
                        'global_batch': world * B, 'parallelism': f'dp{world}',
                        'question_encoder': 'frozen, as the reference trains it; embedding x first LSTM input projection '
                                            + ('tabulated per token id when the weights are loaded' if model.fold_embedding
-                                              else 'computed every step')},
+                                              else 'computed every step')
+                                           + ('; step 1 recurrent product tabulated too' if model.fold_embedding
+                                              and model.fold_first_step else '')},
             'roofline': {'bound': 'hbm', 'kernel': 'k_attn_fwd_online (fused attention forward)', 'achieved': achieved,
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'avg_launch_ms': k6_ms, 'timed_launches': len(ev),

@@ -99,7 +99,11 @@ int vqa_lstm_cell_packed_table(const float* slabs, int nslab, size_t slab_stride
                                int n_table_rows, const int64_t* tokens, float* c, void* h, int ld_h,
                                const int32_t* lengths, float* q_f32, void* q_t, int ld_q, int B, int H, int t, int L,
                                const int32_t* perm, const int32_t* active, const int32_t* offsets, void* hs, int ld_hs,
-                               void* q_drop, unsigned drop_seed, float drop_p, int dtype, hipStream_t stream);
+                               void* q_drop, unsigned drop_seed, float drop_p, const float* hh_table, int dtype,
+                               hipStream_t stream);
+/* (hh_table, optional, fp32 n_table_rows x 4H, only with nslab = 0 and t >= 1: the recurrent product tabulated per
+ *  previous token id, hh_table[v] = h_0(v) W_hh^T with h_0(v) the first step's output for token v; the caller passes it
+ *  at t = 1, the one step whose recurrent input depends on a single token) */
 
 /* Backward through LSTM step t on packed sequences (a trainable question encoder; the reference
  * freezes it, model.py:42-43, so this has no counterpart there beyond autograd of seq2vec.py:43):

@@ -142,7 +142,7 @@ def test_cfg2_fast_paths_agree_with_plain_paths(full_model):
         mm.fuse_row_norm = fast
         mm.swap_big_wgrad = fast
         mm._dpool_from_slabs = fast
-        mm.fold_embedding = fast
+        mm.fold_embedding = mm.fold_first_step = fast
         if not fast:
             mm._launch_early = lambda ws, B: ws.__setitem__('early', {})
 

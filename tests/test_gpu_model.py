@@ -166,9 +166,13 @@ def test_question_encoder_against_reference_fixture(golden_dir, dtype):
     for name in ('main', 'rand'):
         ids = torch.from_numpy(z[f'{name}_ids']).cuda()
         B, L = ids.shape
-        m.fold_embedding = True         # per-token table of input projections (frozen encoder): same question vector
+        m.fold_embedding, m.fold_first_step = True, True     # both per-token tables (frozen encoder)
+        q_both = m.encode_question(ids).clone()
+        assert m._xg_table is not None and m._hh_table is not None
+        assert rel_err(q_both, torch.from_numpy(z[f'{name}_last'])) <= tol
+        m.fold_first_step = False       # table of input projections only: bit-identical to the unfolded path
         q_table = m.encode_question(ids).clone()
-        assert m._xg_table is not None
+        assert m._xg_table is not None and m._hh_table is None
         assert rel_err(q_table, torch.from_numpy(z[f'{name}_last'])) <= tol
         m.fold_embedding = False        # gather + per-step projection: the intermediate gather is checked below
         q = m.encode_question(ids)

@@ -173,11 +173,14 @@ __global__ void __launch_bounds__(256) k_lstm_cell(const float* __restrict__ sla
                             const int* __restrict__ m_t, const int* __restrict__ offs,
                             T* __restrict__ hs, int ld_hs, T* __restrict__ gates_out, float* __restrict__ cs_out,
                             T* __restrict__ q_drop, unsigned seed, unsigned thr, float dscale,
-                            const int64_t* __restrict__ tok = nullptr, int n_table = 0) {
+                            const int64_t* __restrict__ tok = nullptr, int n_table = 0,
+                            const float* __restrict__ hh_table = nullptr) {
     // packed mode (perm != null): state rows are in sorted order, only the first m_t[t] are live, their
     // input-projection rows start at row offs[t] of xg and q goes to the original row perm[b].
     // table mode (tok != null, packed): xg is a table of input projections per token id (a frozen embedding
-    // folded into the frozen W_ih) and the row of sorted row b is xg[tok[perm[b], t]].
+    // folded into the frozen W_ih) and the row of sorted row b is xg[tok[perm[b], t]].  hh_table (table mode, t >= 1,
+    // fp32, same shape): the recurrent product of the previous step's output tabulated per previous token id --
+    // exact only where that output is a function of one token, i.e. at t = 1 (h_0 depends on the first token alone).
     const int H4 = H >> 2;
     const int rows = perm ? m_t[t] : B;
     const long xrow0 = perm ? offs[t] : 0;
@@ -194,6 +197,12 @@ __global__ void __launch_bounds__(256) k_lstm_cell(const float* __restrict__ sla
         f32x4 g[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) g[k] = Vec4<T>::load(xg + (size_t)xrow * ld_xg + k * H + j);
+        if (hh_table) {
+            int64_t pid = tok[(size_t)ob * L + t - 1];
+            if (pid < 0 || pid >= n_table) pid = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) g[k] += Vec4<float>::load(hh_table + (size_t)pid * 4 * H + k * H + j);
+        }
         // the loads of the first four slabs are issued together (a loop with a run-time trip count waits for each)
         if (nslab > 0) {
             f32x4 sv[4][4];
@@ -974,7 +983,9 @@ int vqa_lstm_cell_packed_table(const float* slabs, int nslab, size_t slab_stride
                                int n_table_rows, const int64_t* tokens, float* c, void* h, int ld_h,
                                const int32_t* lengths, float* q_f32, void* q_t, int ld_q, int B, int H, int t, int L,
                                const int32_t* perm, const int32_t* active, const int32_t* offsets, void* hs, int ld_hs,
-                               void* q_drop, unsigned drop_seed, float drop_p, int dtype, hipStream_t stream) {
+                               void* q_drop, unsigned drop_seed, float drop_p, const float* hh_table, int dtype,
+                               hipStream_t stream) {
+    VQA_REQUIRE(!hh_table || (t >= 1 && nslab == 0), "vqa_lstm_cell_packed_table: hh_table replaces the recurrent product of a step t >= 1");
     VQA_REQUIRE(xg_table && tokens && n_table_rows > 0 && c && h && lengths && q_f32 && q_t && perm && active && offsets &&
                 (nslab == 0 || slabs), "vqa_lstm_cell_packed_table: null pointer");
     VQA_REQUIRE(B >= 0 && H > 0 && t >= 0 && t < L && ld_xg >= 4 * H && ld_h >= H && ld_q >= H, "vqa_lstm_cell_packed_table: bad sizes");
@@ -987,7 +998,8 @@ int vqa_lstm_cell_packed_table(const float* slabs, int nslab, size_t slab_stride
     if (B == 0) return 0;
     DISPATCH_T(dtype, (k_lstm_cell<T><<<grid_for((long)B * (H / 4), 256), 256, 0, stream>>>(
         slabs, nslab, slab_stride, (const T*)xg_table, ld_xg, c, (T*)h, ld_h, lengths, q_f32, (T*)q_t, ld_q, B, H, t, L,
-        perm, active, offsets, (T*)hs, ld_hs, (T*)nullptr, nullptr, (T*)q_drop, drop_seed, thr, dsc, tokens, n_table_rows)));
+        perm, active, offsets, (T*)hs, ld_hs, (T*)nullptr, nullptr, (T*)q_drop, drop_seed, thr, dsc, tokens, n_table_rows,
+        hh_table)));
     return vqa_check_launch("vqa_lstm_cell_packed_table");
 }
 

@@ -178,6 +178,7 @@ class _VQAHeadModel(nn.Module):
         self._frozen_key = None
         self._shadow_fresh = False
         self._ctx = None
+        self.fold_first_step = True   # ... and the first recurrent product (h_0 depends on one token)
         self.fold_embedding = True    # frozen encoder: embedding x first input projection tabulated per token id
         self.grad_ready_hook = None   # callable(bucket_index) fired as gradient buckets complete
         self.kernel_events = None     # set to {} to collect per-kernel HIP event pairs
@@ -291,7 +292,7 @@ class _VQAHeadModel(nn.Module):
             ps += [rnn.weight_ih_l0, rnn.weight_hh_l0, rnn.bias_ih_l0, rnn.bias_hh_l0]
         if self.Ec:
             ps.append(self.caption_embedding.weight)
-        key = tuple((p.data_ptr(), p._version) for p in ps) + (str(device), self.fold_embedding, self.train_encoder)
+        key = tuple((p.data_ptr(), p._version) for p in ps) + (str(device), self.fold_embedding, self.fold_first_step, self.train_encoder)
         if key == self._frozen_key:
             return
         tdt = self.compute_dtype
@@ -313,7 +314,7 @@ class _VQAHeadModel(nn.Module):
         # Frozen encoder: embedding followed by the first layer's input projection is one fixed map per token id, so
         # it is tabulated here, once per weight version: xg_table[v] = act(emb[v]) W_ih^T + b_ih + b_hh, computed by
         # the same GEMM kernel on the same rows as the per-step projection it replaces (bit-identical values).
-        self._xg_table = None
+        self._xg_table = self._hh_table = None
         V1, H4 = self._emb_t.shape[0], 4 * self.seq2vec.layers[0].hidden_size
         if self.fold_embedding and not self.train_encoder and V1 * H4 * self._emb_t.element_size() <= (1 << 30):
             wih, _, bias = self._enc_layers[0]
@@ -330,6 +331,24 @@ class _VQAHeadModel(nn.Module):
             call('vqa_gemm_fused', ptr(emb), Ep, 1, ptr(wih), Ep, 1, ptr(table), H4, V1, H4, Ep, ptr(bias), None, 0,
                  self.dt, self.dt, self.gemm_engine)
             self._xg_table = table
+            # ... and so is the first recurrent product: h_0 is a function of the first token alone, so
+            # hh_table[v] = h_0(v) W_hh^T replaces the recurrent GEMM of step 1 (the most expensive one: all rows live,
+            # W_hh cold).  fp32, one K range: equal to the per-step split-K sum up to fp32 rounding of the summation order.
+            self._hh_table = None
+            Hh = H4 // 4
+            if self.fold_first_step and 3 * V1 * H4 * 4 <= (2 << 30):
+                _, whh, _ = self._enc_layers[0]
+                h0 = torch.empty((V1, Hh), dtype=tdt, device=device)
+                c0 = torch.empty((V1, Hh), dtype=torch.float32, device=device)
+                lens = torch.full((V1,), 2, dtype=torch.int32, device=device)     # (no row ends at step 0: q is not written)
+                dq32 = torch.empty((1, Hh), dtype=torch.float32, device=device)
+                dqt = torch.empty((1, Hh), dtype=tdt, device=device)
+                call('vqa_lstm_cell', None, 0, 0, ptr(table), H4, ptr(c0), ptr(h0), Hh, ptr(lens), ptr(dq32), ptr(dqt), Hh,
+                     V1, Hh, 0, 2, self.dt)
+                hh = torch.empty((V1, H4), dtype=torch.float32, device=device)
+                call('vqa_gemm_fused', ptr(h0), Hh, 1, ptr(whh), Hh, 1, ptr(hh), H4, V1, H4, Hh, None, None, 0,
+                     _lib.F32, self.dt, self.gemm_engine)
+                self._hh_table = hh
         self._frozen_key = key
 
     # ------------------------------------------------------------------ workspace
@@ -565,7 +584,8 @@ class _VQAHeadModel(nn.Module):
             q32 = ws['q32'].data_ptr() + 4 * li * Hh            # this layer's columns of q
             qT = ws['qT'].data_ptr() + esz * li * Hh
             for t in range(L):
-                if t == 0:
+                hh_tab = self._hh_table if (from_table and t == 1) else None     # step 1's recurrent product, tabulated
+                if t == 0 or hh_tab is not None:
                     slab, sk, stride = None, 0, 0
                 else:
                     slab, sk, stride = self._gemm_slabs(ws['h'], Hh, 1, whh, Hh, 1, B, 4 * Hh, Hh,
@@ -575,7 +595,7 @@ class _VQAHeadModel(nn.Module):
                          ptr(ws['c']), ptr(ws['h']), Hh, ptr(ws['len']), q32, qT, Hq, B, Hh, t, L, ptr(ws['perm']),
                          ptr(ws['m_t']), ptr(ws['offs']), ptr(hs), Hh,
                          ptr(q_drop[0]) if fuse_drop else None, q_drop[1] if fuse_drop else 0,
-                         q_drop[2] if fuse_drop else 0.0, dt)
+                         q_drop[2] if fuse_drop else 0.0, ptr(hh_tab), dt)
                     continue
                 call('vqa_lstm_cell_packed', ptr(slab), sk, stride, ptr(ws['xg']), 4 * Hh, ptr(ws['c']), ptr(ws['h']), Hh,
                      ptr(ws['len']), q32, qT, Hq, B, Hh, t, L, ptr(ws['perm']), ptr(ws['m_t']),
