@@ -105,6 +105,14 @@ int vqa_lstm_cell_packed_table(const float* slabs, int nslab, size_t slab_stride
  *  previous token id, hh_table[v] = h_0(v) W_hh^T with h_0(v) the first step's output for token v; the caller passes it
  *  at t = 1, the one step whose recurrent input depends on a single token) */
 
+/* Steps 0 and 1 of the table form in one launch (neither needs a recurrent product once hh_table exists): the
+ * outputs of vqa_lstm_cell_packed_table at t = 0 followed by t = 1 with hh_table.  L >= 2. */
+int vqa_lstm_cell01_table(const void* xg_table, int ld_xg, const float* hh_table, int n_table_rows, const int64_t* tokens,
+                          float* c, void* h, int ld_h, const int32_t* lengths, float* q_f32, void* q_t, int ld_q,
+                          int B, int H, int L, const int32_t* perm, const int32_t* active, const int32_t* offsets,
+                          void* hs, int ld_hs, void* q_drop, unsigned drop_seed, float drop_p, int dtype,
+                          hipStream_t stream);
+
 /* Backward through LSTM step t on packed sequences (a trainable question encoder; the reference
  * freezes it, model.py:42-43, so this has no counterpart there beyond autograd of seq2vec.py:43):
  * slabs = dG_{t+1} W_hh partial sums (rows running at t+1), dq (B, ld_dq) in original row order is the

@@ -134,6 +134,10 @@ def test_folded_embedding_table_matches_per_step_projection(arch, dtype):
         assert (m._xg_table is not None) == fold and (m._hh_table is not None) == (fold and first)
         outs.append(q)
     assert torch.equal(outs[0], outs[1])
+    # steps 0 and 1 in one launch against the same two steps launched separately: bit for bit
+    m.fuse_first_two_cells = False
+    q_sep = m.encode_question(tok.cuda()).clone()
+    assert torch.equal(q_sep, outs[2])
     # the tabulated first recurrent product is one fp32 sum per element instead of a split-K sum: equal up to rounding
     err = float((outs[2] - outs[1]).abs().max() / outs[1].abs().max())
     assert err <= (1e-5 if dtype == torch.float32 else 1e-2), err

@@ -259,6 +259,79 @@ __global__ void __launch_bounds__(256) k_lstm_cell(const float* __restrict__ sla
     }
 }
 
+// Steps 0 and 1 of a frozen first layer in one launch: neither needs a recurrent GEMM when the input projections
+// (xg_table) and the first recurrent product (hh_table) are tabulated per token id.  Same arithmetic and the same
+// outputs as k_lstm_cell in table mode at t = 0 followed by t = 1 (packed rows; rows live at step 1 are a prefix
+// of the rows live at step 0).
+template <typename T>
+__global__ void __launch_bounds__(256) k_lstm_cell01_table(const T* __restrict__ xg, int ld_xg, const float* __restrict__ hh_table,
+                            int n_table, const int64_t* __restrict__ tok, float* __restrict__ c, T* __restrict__ h, int ld_h,
+                            const int* __restrict__ len, float* __restrict__ q32, T* __restrict__ qT, int ld_q,
+                            int H, int L, const int* __restrict__ perm, const int* __restrict__ m_t,
+                            const int* __restrict__ offs, T* __restrict__ hs, int ld_hs,
+                            T* __restrict__ q_drop, unsigned seed, unsigned thr, float dscale) {
+    const int H4 = H >> 2;
+    const int rows0 = m_t[0], rows1 = m_t[1];
+    const long total = (long)rows0 * H4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / H4), j = (int)(i % H4) * 4;
+        const int ob = perm[b];
+        int64_t id0 = tok[(size_t)ob * L];
+        if (id0 < 0 || id0 >= n_table) id0 = 0;
+        int64_t id1 = tok[(size_t)ob * L + 1];
+        if (id1 < 0 || id1 >= n_table) id1 = 0;
+        const bool second = b < rows1;
+        f32x4 g[4], g1[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) g[k] = Vec4<T>::load(xg + (size_t)id0 * ld_xg + k * H + j);
+        if (second) {                       // requested before step 0's arithmetic: both gathers are in flight together
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                g1[k] = Vec4<T>::load(xg + (size_t)id1 * ld_xg + k * H + j);
+                g1[k] += Vec4<float>::load(hh_table + (size_t)id0 * 4 * H + k * H + j);
+            }
+        }
+        int last = len[ob] - 1;
+        if (last < 0) last += L;
+        f32x4 cn, hn;
+        auto emit = [&](int t) {            // what k_lstm_cell stores for step t
+            if (hs) Vec4<T>::store(hs + (size_t)(offs[t] + b) * ld_hs + j, hn);
+            if (last == t) {
+                Vec4<float>::store(q32 + (size_t)ob * ld_q + j, hn);
+                Vec4<T>::store(qT + (size_t)ob * ld_q + j, hn);
+                if (q_drop) {
+                    f32x4 qd;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        qd[e] = to_f32<T>(from_f32<T>(hn[e])) * drop_mult(seed, (unsigned)(ob * H + j + e), thr, dscale);
+                    Vec4<T>::store(q_drop + (size_t)ob * ld_q + j, qd);
+                }
+            }
+        };
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float ig = Act<T>::sigm_(g[0][e]), fg = Act<T>::sigm_(g[1][e]);
+            const float gg = Act<T>::tanh_(g[2][e]), og = Act<T>::sigm_(g[3][e]);
+            cn[e] = fg * 0.f + ig * gg;      // (as the one-step kernel: f * c_prev with c_prev = 0)
+            hn[e] = og * Act<T>::tanh_(cn[e]);
+        }
+        emit(0);
+        if (second) {
+            // the one-step kernel reads h_0 back only through the recurrent product, and c_0 as stored fp32
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float ig = Act<T>::sigm_(g1[0][e]), fg = Act<T>::sigm_(g1[1][e]);
+                const float gg = Act<T>::tanh_(g1[2][e]), og = Act<T>::sigm_(g1[3][e]);
+                cn[e] = fg * cn[e] + ig * gg;
+                hn[e] = og * Act<T>::tanh_(cn[e]);
+            }
+            emit(1);
+        }
+        Vec4<float>::store(c + (size_t)b * H + j, cn);
+        Vec4<T>::store(h + (size_t)b * ld_h + j, hn);
+    }
+}
+
 // caption vector: masked mean of the gathered rows, then L2 normalise; one
 // block per sample; written into columns [col0, col0 + Ec) of out.
 template <typename T>
@@ -1001,6 +1074,27 @@ int vqa_lstm_cell_packed_table(const float* slabs, int nslab, size_t slab_stride
         perm, active, offsets, (T*)hs, ld_hs, (T*)nullptr, nullptr, (T*)q_drop, drop_seed, thr, dsc, tokens, n_table_rows,
         hh_table)));
     return vqa_check_launch("vqa_lstm_cell_packed_table");
+}
+
+int vqa_lstm_cell01_table(const void* xg_table, int ld_xg, const float* hh_table, int n_table_rows, const int64_t* tokens,
+                          float* c, void* h, int ld_h, const int32_t* lengths, float* q_f32, void* q_t, int ld_q,
+                          int B, int H, int L, const int32_t* perm, const int32_t* active, const int32_t* offsets,
+                          void* hs, int ld_hs, void* q_drop, unsigned drop_seed, float drop_p, int dtype,
+                          hipStream_t stream) {
+    VQA_REQUIRE(xg_table && hh_table && tokens && n_table_rows > 0 && c && h && lengths && q_f32 && q_t && perm && active &&
+                offsets, "vqa_lstm_cell01_table: null pointer");
+    VQA_REQUIRE(B >= 0 && H > 0 && L >= 2 && ld_xg >= 4 * H && ld_h >= H && ld_q >= H, "vqa_lstm_cell01_table: bad sizes");
+    VQA_REQUIRE(H % 4 == 0 && ld_xg % 4 == 0 && ld_h % 4 == 0 && ld_q % 4 == 0,
+                "vqa_lstm_cell01_table: H and leading dimensions must be multiples of 4");
+    VQA_REQUIRE(!hs || (ld_hs >= H && ld_hs % 4 == 0), "vqa_lstm_cell01_table: bad ld_hs");
+    VQA_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "vqa_lstm_cell01_table: drop_p must be in [0, 1)");
+    const unsigned thr = drop_threshold(drop_p);
+    const float dsc = 1.0f / (1.0f - drop_p);
+    if (B == 0) return 0;
+    DISPATCH_T(dtype, (k_lstm_cell01_table<T><<<grid_for((long)B * (H / 4), 256), 256, 0, stream>>>(
+        (const T*)xg_table, ld_xg, hh_table, n_table_rows, tokens, c, (T*)h, ld_h, lengths, q_f32, (T*)q_t, ld_q, H, L,
+        perm, active, offsets, (T*)hs, ld_hs, (T*)q_drop, drop_seed, thr, dsc)));
+    return vqa_check_launch("vqa_lstm_cell01_table");
 }
 
 int vqa_lstm_cell(const float* slabs, int nslab, size_t slab_stride, const void* xg_t, int ld_xg, float* c,

@@ -179,6 +179,7 @@ class _VQAHeadModel(nn.Module):
         self._shadow_fresh = False
         self._ctx = None
         self.fold_first_step = True   # ... and the first recurrent product (h_0 depends on one token)
+        self.fuse_first_two_cells = True   # steps 0 and 1 then run as one launch
         self.fold_embedding = True    # frozen encoder: embedding x first input projection tabulated per token id
         self.grad_ready_hook = None   # callable(bucket_index) fired as gradient buckets complete
         self.kernel_events = None     # set to {} to collect per-kernel HIP event pairs
@@ -583,7 +584,15 @@ class _VQAHeadModel(nn.Module):
                      L * B, 4 * Hh, kin, ptr(bias), None, 0, dt, dt, self.gemm_engine, total_rows)
             q32 = ws['q32'].data_ptr() + 4 * li * Hh            # this layer's columns of q
             qT = ws['qT'].data_ptr() + esz * li * Hh
-            for t in range(L):
+            t_first = 0
+            if from_table and self._hh_table is not None and L >= 2 and self.fuse_first_two_cells:   # no GEMM between them
+                call('vqa_lstm_cell01_table', ptr(table), 4 * Hh, ptr(self._hh_table), table.shape[0], ptr(tokens),
+                     ptr(ws['c']), ptr(ws['h']), Hh, ptr(ws['len']), q32, qT, Hq, B, Hh, L, ptr(ws['perm']),
+                     ptr(ws['m_t']), ptr(ws['offs']), ptr(hs), Hh,
+                     ptr(q_drop[0]) if fuse_drop else None, q_drop[1] if fuse_drop else 0,
+                     q_drop[2] if fuse_drop else 0.0, dt)
+                t_first = 2
+            for t in range(t_first, L):
                 hh_tab = self._hh_table if (from_table and t == 1) else None     # step 1's recurrent product, tabulated
                 if t == 0 or hh_tab is not None:
                     slab, sk, stride = None, 0, 0
