@@ -400,6 +400,12 @@ class _VQAHeadModel(nn.Module):
     def _linear(self, x, ldx, wname, bname, M, N, K, *, act=0, out_pre=None, ld_pre=0, out_post=None, ld_post=0,
                 post_dtype=None, addend=None, ld_add=0, seed=0, p=0.0):
         """epilogue(x W^T + b) for a small-M product (split-K slabs + fused reduce)."""
+        if (act == 0 and addend is None and out_post is None and out_pre is not None
+                and call('vqa_gemm_splitk_hint', M, N, K, 1, 1) == 1):
+            # one K range and a plain bias: the product's own epilogue writes the result (no reduce launch)
+            call('vqa_gemm_fused', ptr(x), ldx, 1, ptr(self._w(wname)), K, 1, ptr(out_pre), ld_pre, M, N, K,
+                 ptr(self._f32(bname)) if bname else None, None, 0, _lib.F32, self.dt, self.gemm_engine)
+            return
         slab, sk, stride = self._gemm_slabs(x, ldx, 1, self._w(wname), K, 1, M, N, K)
         call('vqa_epilogue', ptr(slab), sk, stride, M, N, ptr(self._f32(bname)) if bname else None, None,
              ptr(addend), ld_add, act, ptr(out_pre), ld_pre, ptr(out_post), ld_post,
