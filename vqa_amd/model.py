@@ -96,11 +96,20 @@ class _VQAFunction(torch.autograd.Function):
         logits = model._forward_impl(feats, tokens, captions).clone()
         ctx.model = model
         ctx.n_params = len(params)
+        ctx.generation = model._generation
         return logits
 
     @staticmethod
     def backward(ctx, dlogits):
         model = ctx.model
+        if ctx.generation != model._generation:
+            # the activations this node needs live in the module's workspace and the forward that ran in
+            # between has overwritten them (one forward is in flight per module)
+            raise RuntimeError(
+                f'{type(model).__name__}: backward() of forward #{ctx.generation} called after forward '
+                f'#{model._generation} of the same module; the module keeps the activations of its latest forward '
+                'only. Call backward() before the next forward (an evaluation forward included), as '
+                'train.py:200-204 does, or use a second module instance.')
         model._backward_from_dense(dlogits)
         grads = [v.clone() for v in model._grad_views]
         return (None, None, None, None, *grads)
@@ -178,6 +187,7 @@ class _VQAHeadModel(nn.Module):
         self._frozen_key = None
         self._shadow_fresh = False
         self._ctx = None
+        self._generation = 0          # forwards run so far; an autograd node belongs to exactly one of them
         self.fold_first_step = True   # ... and the first recurrent product (h_0 depends on one token)
         self.fuse_first_two_cells = True   # steps 0 and 1 then run as one launch
         self.fold_embedding = True    # frozen encoder: embedding x first input projection tabulated per token id
@@ -227,6 +237,11 @@ class _VQAHeadModel(nn.Module):
                     break
         if ok:
             return
+        # Adam moments of an earlier layout (the module was moved after training had started) follow by name
+        moments = None
+        if getattr(self, '_exp_avg', None) is not None and getattr(self, '_index', None):
+            moments = {name: (self._exp_avg[o:o + n].to(device), self._exp_avg_sq[o:o + n].to(device))
+                       for name, (o, n, _) in self._index.items()}
         offsets, total = [], 0
         for _, p in order:
             offsets.append((total, p.numel()))
@@ -243,8 +258,14 @@ class _VQAHeadModel(nn.Module):
         self._flat, self._flat_grad, self._offsets = flat, grad, offsets
         self._shadow = torch.zeros(total, dtype=torch.bfloat16, device=device) if self.dt == _lib.BF16 else None
         self._exp_avg = self._exp_avg_sq = None
+        if moments is not None and all(name in moments and moments[name][0].numel() == n
+                                       for name, (o, n, _) in self._index.items()):
+            self._exp_avg, self._exp_avg_sq = torch.zeros_like(flat), torch.zeros_like(flat)
+            for name, (o, n, _) in self._index.items():
+                self._exp_avg[o:o + n].copy_(moments[name][0])
+                self._exp_avg_sq[o:o + n].copy_(moments[name][1])
         self._shadow_fresh = False
-        self._shadow_version = -1
+        self._shadow_version = None
         # bucket boundaries (element ranges of the flat buffer) in completion order
         names = [n for n, _ in order]
         enc = [self._encoder_trainable_order()[0][0]] if self.train_encoder else []
@@ -272,18 +293,30 @@ class _VQAHeadModel(nn.Module):
         o, n, _ = self._index[name]
         return self._flat_grad[o:o + n]
 
+    def _param_versions(self):
+        """Version counters of the flat buffer and of every parameter view of it.  The parameters are attached
+        with ``p.data = view``, which gives each its own counter: torch.optim.Adam.step() (train.py:204),
+        ``p.add_()`` or ``p.copy_()`` move the parameter's counter and leave the flat buffer's alone."""
+        return (self._flat._version,) + tuple(p._version for _, p in self._trainable_order())
+
+    def _mark_shadow_fresh(self):
+        """The fused Adam kernel has just written the bf16 copies itself (through raw pointers: no counter moved)."""
+        self._shadow_fresh = self.dt == _lib.BF16
+        self._shadow_version = self._param_versions()
+
     def _refresh_shadow(self):
-        """bf16 copies of the trainable weights.  The fused Adam kernel writes them
-        itself; any torch-side in-place update of a parameter bumps the flat
-        buffer's version counter and triggers a re-cast here."""
+        """bf16 copies of the trainable weights.  The fused Adam kernel writes them itself; any torch-side in-place
+        update of a parameter (the reference's optimizer.step(), train.py:204) moves that parameter's version
+        counter and triggers a re-cast here."""
         if self.dt != _lib.BF16:
             return
-        if self._shadow_fresh and self._shadow_version == self._flat._version:
+        versions = self._param_versions()
+        if self._shadow_fresh and self._shadow_version == versions:
             return
         n = self._flat.numel()
         call('vqa_cast_pad', ptr(self._flat), n, ptr(self._shadow), n, 1, n, _lib.BF16)
         self._shadow_fresh = True
-        self._shadow_version = self._flat._version
+        self._shadow_version = versions
 
     def _refresh_frozen(self, device):
         """Compute-dtype copies of the frozen question / caption encoder weights: embedding table and
@@ -705,6 +738,7 @@ class _VQAHeadModel(nn.Module):
         self._linear(ws['h1d'], Hf, 'linear_classif2.weight', 'linear_classif2.bias', B, C, Hf,
                      out_pre=ws['logits'], ld_pre=Cp)
         self._ctx = (ws, feats, B, L, seeds, p)
+        self._generation += 1
         return ws['logits'][:, :C]
 
     # ------------------------------------------------------------------ backward
@@ -855,8 +889,7 @@ class _VQAHeadModel(nn.Module):
         self._finish_pending()
         self.step_count += 1
         self._adam_range(0, self._flat.numel(), lr, betas, eps, self.step_count, grad_scale)
-        self._shadow_fresh = self.dt == _lib.BF16
-        self._shadow_version = self._flat._version
+        self._mark_shadow_fresh()
 
     def _finish_pending(self):
         """Complete a train_step whose last gradient bucket was left in flight: wait for its
@@ -898,16 +931,14 @@ class _VQAHeadModel(nn.Module):
                 scale = reducer.defer_everything()       # nothing is waited for inside the step
                 self.step_count += 1
                 self._pending = (reducer, 0, self._flat.numel(), lr, betas, eps, self.step_count, scale)
-                self._shadow_fresh = self.dt == _lib.BF16
-                self._shadow_version = self._flat._version
+                self._mark_shadow_fresh()
             elif reducer is not None and reducer.enabled and reducer.defer_last and len(self.buckets) > 1:
                 scale = reducer.finish(defer_last=True)
                 lo, hi = self.buckets[-1]
                 self.step_count += 1
                 self._adam_range(0, lo, lr, betas, eps, self.step_count, scale)
                 self._pending = (reducer, lo, hi, lr, betas, eps, self.step_count, scale)
-                self._shadow_fresh = self.dt == _lib.BF16
-                self._shadow_version = self._flat._version
+                self._mark_shadow_fresh()
             else:
                 scale = reducer.finish() if reducer is not None else 1.0
                 self.adam_step(lr, betas, eps, grad_scale=scale)
