@@ -183,6 +183,17 @@ int vqa_grid_mean_splits(int layout, int B, int C, int HW);
 int vqa_grid_mean(const void* x, int layout, int B, int C, int HW, float* out, int ld_out, int col0,
                   float* partial, int nsplit, int dtype, hipStream_t stream);
 
+/* vqa_grid_mean for callers that cannot allocate device memory or pass a workspace (code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  The split count is
+ * vqa_grid_mean_splits(layout, B, C, HW) and the partial sums live in a static device array of
+ * VQA_GRID_MEAN_STATIC_FLOATS floats (1 MiB, held by every GPU the library runs on until the process ends);
+ * nsplit * B * C beyond that returns -22.  Same results as vqa_grid_mean, bit for bit.  The call allocates and
+ * frees nothing; the first call on a device looks the array's address up (hipGetSymbolAddress).  All calls on
+ * one GPU share the array: calls that overlap on one GPU (two streams, two threads) race. */
+#define VQA_GRID_MEAN_STATIC_FLOATS (1 << 18)
+int vqa_grid_mean_static(const void* x, int layout, int B, int C, int HW, float* out, int ld_out, int col0,
+                         int dtype, hipStream_t stream);
+
 /* gate[b,n] = sigmoid(sum_s slabs[s][b][n] + bias[n]);  out[b,n] = dropout(mean[b,n] * gate[b,n])
  *                     model.py:125-140 (gapK = Linear + Sigmoid), 166-172 (product, cat, dropoutV) */
 int vqa_gate_fwd(const float* slabs, int nslab, size_t slab_stride, const float* bias, const float* mean, int ld_mean,

@@ -38,6 +38,7 @@ _SIGNATURES = {
     'vqa_inv_norm': [_p, _p, _l, _i, _i, _i, _p],
     'vqa_grid_mean_splits': [_i, _i, _i, _i],
     'vqa_grid_mean': [_p, _i, _i, _i, _i, _p, _i, _i, _p, _i, _i, _p],
+    'vqa_grid_mean_static': [_p, _i, _i, _i, _i, _p, _i, _i, _i, _p],
     'vqa_gate_fwd': [_p, _i, _z, _p, _p, _i, _p, _i, _p, _i, _i, _i, _u, _f, _i, _p],
     'vqa_gate_bwd': [_p, _i, _p, _i, _p, _i, _p, _i, _i, _i, _i, _p],
     'vqa_stack_maxavg_fwd': [_p, _p, _i, _p, _i, _p, _i, _i, _i, _u, _f, _i, _p],

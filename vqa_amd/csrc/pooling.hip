@@ -6,6 +6,7 @@
 // All kernels are HBM-streaming: 16-byte accesses, fp32 accumulation, fixed summation order.
 #include "common.h"
 #include "vqa_hip.h"
+#include <mutex>
 
 // ---------------------------------------------------------------------------
 // grid mean, rows layout: x is (rows = B * C) x HW contiguous (an NCHW map); out[b, col0 + c].
@@ -240,6 +241,13 @@ static inline int grid_for(long total, int block, int cap = 2048) {
     return (int)g;
 }
 
+// Scratch of vqa_grid_mean_static: split partial sums, [split][b][c] floats.  In host code this name is only a
+// handle for hipGetSymbolAddress; kernels receive the per-device address that call returned.
+static __device__ __align__(256) float grid_mean_static_scratch[VQA_GRID_MEAN_STATIC_FLOATS];
+static constexpr int kMaxDevices = 64;
+static float* g_static_scratch_ptr[kMaxDevices] = {};
+static std::mutex g_static_scratch_mutex;
+
 #define DISPATCH_T(dtype, CALL)                                      \
     if ((dtype) == VQA_F32) { using T = float; CALL; }              \
     else if ((dtype) == VQA_BF16) { using T = bf16_t; CALL; }       \
@@ -278,6 +286,39 @@ int vqa_grid_mean(const void* x, int layout, int B, int C, int HW, float* out, i
     if (nsplit > 1)
         k_grid_mean_finish<<<grid_for((long)B * C, 256), 256, 0, stream>>>(partial, out, B, C, HW, ld_out, col0, nsplit);
     return vqa_check_launch("vqa_grid_mean");
+}
+
+// vqa_grid_mean for callers that cannot allocate: the split partial sums of the channels-last layout live in a
+// file-scope device array instead of a caller-provided workspace.  Every GPU holds its own copy of the array at
+// its own address; the address is looked up once per device (first call with that device current) and kept.
+int vqa_grid_mean_static(const void* x, int layout, int B, int C, int HW, float* out, int ld_out, int col0,
+                         int dtype, hipStream_t stream) {
+    VQA_REQUIRE(x && out && B >= 0 && C > 0 && HW > 0, "vqa_grid_mean_static: bad arguments");
+    if (B == 0) return 0;
+    const int nsplit = vqa_grid_mean_splits(layout, B, C, HW);
+    float* part = nullptr;
+    if (nsplit > 1) {
+        if ((long)nsplit * B * C > (long)VQA_GRID_MEAN_STATIC_FLOATS)
+            return vqa_set_error(-22, "vqa_grid_mean_static: nsplit * B * C partial sums exceed the static scratch "
+                                      "(VQA_GRID_MEAN_STATIC_FLOATS floats); use vqa_grid_mean with a workspace");
+        int dev = -1;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess || dev < 0 || dev >= kMaxDevices)
+            return vqa_set_error(-1000 - (int)e, "vqa_grid_mean_static: hipGetDevice failed or device index >= 64");
+        {
+            std::lock_guard<std::mutex> lock(g_static_scratch_mutex);
+            if (!g_static_scratch_ptr[dev]) {
+                void* p = nullptr;
+                e = hipGetSymbolAddress(&p, HIP_SYMBOL(grid_mean_static_scratch));
+                if (e != hipSuccess || !p)
+                    return vqa_set_error(-1000 - (int)e, "vqa_grid_mean_static: hipGetSymbolAddress(scratch) failed");
+                g_static_scratch_ptr[dev] = (float*)p;
+            }
+            part = g_static_scratch_ptr[dev];
+        }
+    }
+    // every partial sum the finish kernel reads is written by this call's first kernel: nothing to clear
+    return vqa_grid_mean(x, layout, B, C, HW, out, ld_out, col0, part, nsplit, dtype, stream);
 }
 
 int vqa_gate_fwd(const float* slabs, int nslab, size_t slab_stride, const float* bias, const float* mean, int ld_mean,
