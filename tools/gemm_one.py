@@ -9,6 +9,12 @@ if which == 'k4':
     M, N, K, akm, bkm, sk = 50176, 1200, 2048, 1, 1, 1
 elif which == 'wgrad':
     M, N, K, akm, bkm, sk = 1200, 2048, 50176, 0, 0, 3
+elif which == 'wgrad_swapped':
+    M, N, K, akm, bkm, sk = 2048, 1200, 50176, 0, 0, 6
+elif which == 'sq4k':
+    M, N, K, akm, bkm, sk = 4096, 4096, 4096, 1, 1, 1
+elif which == 'sq8k':
+    M, N, K, akm, bkm, sk = 8192, 8192, 8192, 1, 1, 1
 else:
     M, N, K, akm, bkm, sk = 256, 9600, 2400, 1, 1, 3
 A = (torch.randn((M, K) if akm else (K, M), device='cuda') * 0.5).to(dt)

@@ -14,6 +14,18 @@ def timeit(fn, n=10, warm=2):
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / n * 1e3
 
+def run_fused(name, M, N, K, engines, ldc=None):
+    """the projection as the step calls it: bf16 output, bias and row scale in the epilogue"""
+    dt = torch.bfloat16
+    A = (torch.randn((M, K), device='cuda') * 0.5).clamp_min_(0).to(dt)
+    Bm = (torch.randn((N, K), device='cuda') * 0.05).to(dt)
+    bias = torch.randn(N, device='cuda'); rs = torch.rand(M, device='cuda')
+    ldc = ldc or N
+    C = torch.empty((M, ldc), device='cuda', dtype=dt)
+    for eng in engines:
+        us = timeit(lambda: call('vqa_gemm_fused', ptr(A), K, 1, ptr(Bm), K, 1, ptr(C), ldc, M, N, K, ptr(bias), ptr(rs), 0, 1, 1, eng))
+        print(f'{name:12s} fused bf16 out ldc={ldc} M={M:6d} N={N:5d} K={K:6d} engine={eng:2d}: {us:8.1f} us  {2.0 * M * N * K / us / 1e6:7.1f} TF')
+
 def run(name, M, N, K, akm, bkm, variants):
     dt = torch.bfloat16
     A = (torch.randn((M, K) if akm else (K, M), device='cuda') * 0.5).to(dt)
@@ -22,7 +34,7 @@ def run(name, M, N, K, akm, bkm, variants):
     slab = torch.empty(max(v[1] for v in variants) * M * N, device='cuda', dtype=torch.float32)
     for eng, sk in variants:
         us = timeit(lambda: call('vqa_gemm_slabs', ptr(A), lda, int(akm), ptr(Bm), ldb, int(bkm), ptr(slab), M * N, N, M, N, K, sk, 1, eng))
-        print(f'{name:12s} M={M:6d} N={N:5d} K={K:6d} tile={ {2: "64", 3: "128", 4: "256x128", 6: "256x256", 8: "256x256r10", 9: "256x256r10pf"}[eng] } splitk={sk:2d}: {us:8.1f} us  {2.0 * M * N * K / us / 1e6:7.1f} TF')
+        print(f'{name:12s} M={M:6d} N={N:5d} K={K:6d} tile={ {2: "64", 3: "128", 4: "256x128", 6: "256x256", 8: "256x256r10", 9: "256x256r10pf", 10: "256x256pp"}[eng] } splitk={sk:2d}: {us:8.1f} us  {2.0 * M * N * K / us / 1e6:7.1f} TF')
 
 if __name__ == '__main__':
     which = sys.argv[1] if len(sys.argv) > 1 else 'big'
@@ -32,6 +44,20 @@ if __name__ == '__main__':
             run('square', 8192, 8192, 8192, True, True, [(6, 1), (8, 1), (9, 1)])
             run('wgrad TN', 1200, 2048, 50176, False, False, [(6, 6), (8, 6), (9, 6), (4, 3), (6, 5), (6, 7)])
             run('wgrad TN swapped', 2048, 1200, 50176, False, False, [(6, 6), (8, 6), (4, 3)])
+    elif which == 'pp':
+        for _ in range(3):
+            run('K4 fwd NT', 50176, 1200, 2048, True, True, [(9, 1), (10, 1)])
+            run('sq4k', 4096, 4096, 4096, True, True, [(9, 1), (10, 1)])
+            run('square', 8192, 8192, 8192, True, True, [(9, 1), (10, 1)])
+            run('wgrad TN swapped', 2048, 1200, 50176, False, False, [(6, 6), (10, 6)])
+    elif which == 'pp10':
+        for _ in range(3):
+            engs = [int(e) for e in (sys.argv[2] if len(sys.argv) > 2 else '10').split(',')]
+            run_fused('K4 fwd', 50176, 1200, 2048, engs)
+            run_fused('K4 fwd', 50176, 1200, 2048, engs, ldc=1280)
+            run('K4 fwd NT', 50176, 1200, 2048, True, True, [(10, 1)])
+            run('sq4k', 4096, 4096, 4096, True, True, [(10, 1)])
+            run('square', 8192, 8192, 8192, True, True, [(10, 1)])
     elif which == 'probe':
         for _ in range(2):
             run('K4 fwd NT', 50176, 1200, 2048, True, True, [(9, 1)])

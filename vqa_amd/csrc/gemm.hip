@@ -19,6 +19,8 @@
 #include "common.h"
 #include "vqa_hip.h"
 #include "colsum.h"
+#include <type_traits>
+#include <cstdlib>
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
@@ -203,7 +205,9 @@ __device__ __forceinline__ bf16x8_t frag_read(const char* lds, int r0, int kk, i
 // Accumulators -> global through LDS so that every store instruction writes whole 64..256-byte
 // row segments.  Each wave stages 32 rows of its (BM/2 x BN/2) tile at a time as fp32.
 // FS = distance in rows between a wave's consecutive 16-row fragments (16: one contiguous band).
-template <int MT, int NT, int FS = 16>
+// NTS: the 16-byte output stores are non-temporal (a compile-time choice: behind a run-time condition the compiler
+// merges the two store forms and drops the hint)
+template <int MT, int NT, int FS = 16, bool NTS = false>
 __device__ __forceinline__ void epilogue_store(char* lds, f32x4 (&acc)[MT][NT], const Epi& epi, int split,
                                                int m_w, int n_w, int M, int N, int wave, int lane,
                                                const float* rs_tile = nullptr, int m_tile0 = 0) {
@@ -244,11 +248,15 @@ __device__ __forceinline__ void epilogue_store(char* lds, f32x4 (&acc)[MT][NT], 
                 const f32x4 a = *reinterpret_cast<const f32x4*>(wl + rl * LDW + c);
                 const f32x4 b = *reinterpret_cast<const f32x4*>(wl + rl * LDW + c + 4);
                 bf16_t* dst = out + (size_t)m * epi.ld + n;
+#if defined(PP_PROBE) && PP_PROBE == 4
+                if (a[0] + b[3] != 123.456f) continue;      // probe build: staging without the global stores (timing only)
+#endif
                 if (vec_ok && n + 8 <= N) {
                     u16x8 o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { o[e] = f32_to_bf16(a[e]); o[4 + e] = f32_to_bf16(b[e]); }
-                    *reinterpret_cast<u16x8*>(dst) = o;
+                    if (NTS) __builtin_nontemporal_store(o, reinterpret_cast<u16x8*>(dst));
+                    else *reinterpret_cast<u16x8*>(dst) = o;
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -268,7 +276,8 @@ __device__ __forceinline__ void epilogue_store(char* lds, f32x4 (&acc)[MT][NT], 
                 const f32x4 a = *reinterpret_cast<const f32x4*>(wl + rl * LDW + c);
                 float* dst = out + (size_t)m * epi.ld + n;
                 if (vec_ok && n + 4 <= N) {
-                    *reinterpret_cast<f32x4*>(dst) = a;
+                    if (NTS) __builtin_nontemporal_store(a, reinterpret_cast<f32x4*>(dst));
+                    else *reinterpret_cast<f32x4*>(dst) = a;
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
@@ -780,6 +789,297 @@ k_gemm_bf16_r10(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict_
     epilogue_store<MT, NT>(lds, acc, epi, split, m0 + wm * 128, n0 + wn * 64, M, N, wave, lane);
 }
 
+// ---- 256 x 256 tiles, eight phases per pair of K tiles, two wave groups half a phase apart ----------
+// Same ring of ten 16 KiB quarter-operand slots as above (quarter order per K tile: B columns 0-127, B columns
+// 128-255, A rows 0-127, A rows 128-255), but the K tile is cut into four phases of 16 MFMAs per wave (one
+// 64 x 32 quadrant of the wave's 128 x 64 output over the whole K tile), each phase being
+//     fragment reads of that quadrant + one quarter's LDS-DMA | barrier | 16 MFMAs | barrier
+// and waves 4-7 run one barrier behind waves 0-3 (they share the SIMDs pairwise), so that on every SIMD one wave
+// multiplies while its partner reads LDS and issues DMA.  Quarter 4 t + p + 7 is issued in phase p of tile t: three
+// quarters stay in flight across the tile boundary (one counted wait per K tile, never a drain), and a slot is
+// refilled no sooner than two phases after its last fragment read.
+// Every wave executes the same number of barriers: 1 + 8 nk + 1 + 1.
+// Column permutation of the eight-phase kernel's bf16 epilogue: with the B fragment as the first MFMA operand a lane
+// (g = lane >> 4, c = lane & 15) ends up with C[row 16 i + c][slab position 16 j + 4 g + r] in acc[i][j][r]; slab
+// position p holds output column sigma(p) = 32 (j >> 1) + 8 g + 4 (j & 1) + r, so fragments j = 0, 1 (and 2, 3) of a
+// lane are 8 consecutive columns.
+__device__ __forceinline__ int pp_sigma(int p) {
+    const int j = p >> 4, g = (p >> 2) & 3, r = p & 3;
+    return 32 * (j >> 1) + 8 * g + 4 * (j & 1) + r;
+}
+
+// Accumulators -> global straight from the registers (no LDS staging, no barrier): bf16 output as 16-byte stores of 8
+// consecutive columns (16 rows x 64 bytes per store instruction), fp32 output as 16-byte stores of a fragment's 4
+// columns (16 rows x 64 bytes).  m_w: first row of the wave's 128 inside the tile; n_w: the wave's first column.
+template <bool NTS>
+__device__ __forceinline__ void pp_store(f32x4 (&acc)[8][4], const Epi& epi, int split, int m0, int m_w, int n_w, int M, int N,
+                                         int lane, const float* rs_tile, bool perm) {
+    const int g = lane >> 4, c = lane & 15;
+    const bool vec_ok = ((((size_t)epi.ld * (epi.out_bf16 ? 2 : 4)) & 15) == 0) && ((((uintptr_t)epi.out) & 15) == 0) &&
+                        (((epi.split_stride * 4) & 15) == 0);
+    if (perm) {
+        // columns n_w + 32 h + 8 g + e, e = 0..7, h = 0, 1
+        float bias[2][8];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int n = n_w + 32 * h + 8 * g + e;
+                bias[h][e] = (epi.bias && n < N) ? epi.bias[n] : 0.f;
+            }
+        bf16_t* out = (bf16_t*)epi.out;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int m = m0 + m_w + 16 * i + c;
+            if (m >= M) continue;
+            const float rs = rs_tile ? rs_tile[m_w + 16 * i + c] : (epi.row_scale ? epi.row_scale[m] : 1.f);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int n = n_w + 32 * h + 8 * g;
+                if (n >= N) continue;
+                u16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = f32_to_bf16(epi.value(acc[i][2 * h + (e >> 2)][e & 3], rs, bias[h][e]));
+                bf16_t* dst = out + (size_t)m * epi.ld + n;
+                if (vec_ok && n + 8 <= N) {
+                    if (NTS) __builtin_nontemporal_store(o, reinterpret_cast<u16x8*>(dst));
+                    else *reinterpret_cast<u16x8*>(dst) = o;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (n + e < N) dst[e] = o[e];
+                }
+            }
+        }
+        return;
+    }
+    // identity column order: acc[i][j][r] = C[16 i + c][16 j + 4 g + r]
+    float bias[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = n_w + 16 * j + 4 * g + r;
+            bias[j][r] = (epi.bias && n < N) ? epi.bias[n] : 0.f;
+        }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int m = m0 + m_w + 16 * i + c;
+        if (m >= M) continue;
+        const float rs = rs_tile ? rs_tile[m_w + 16 * i + c] : (epi.row_scale ? epi.row_scale[m] : 1.f);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n_w + 16 * j + 4 * g;
+            if (n >= N) continue;
+            f32x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = epi.value(acc[i][j][r], rs, bias[j][r]);
+            if (epi.out_bf16) {
+                bf16_t* dst = (bf16_t*)epi.out + (size_t)m * epi.ld + n;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (n + r < N) dst[r] = f32_to_bf16(v[r]);
+            } else {
+                float* dst = (float*)epi.out + split * epi.split_stride + (size_t)m * epi.ld + n;
+                if (vec_ok && n + 4 <= N) {
+                    if (NTS) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(dst));
+                    else *reinterpret_cast<f32x4*>(dst) = v;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (n + r < N) dst[r] = v[r];
+                }
+            }
+        }
+    }
+}
+
+template <bool AKM, bool BKM, bool NORM, bool NTS = false>
+__global__ void __launch_bounds__(512)
+k_gemm_bf16_pp(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, int M, int N, int K,
+               int tiles_m, int tiles_n, int k_per_split, Epi epi) {
+    constexpr int BM = 256, BN = 256, NW = 8, NQ = 10, QB = 16384;
+    typedef Tile<128, AKM> TA;
+    typedef Tile<128, BKM> TB;
+    static_assert(TA::BYTES == QB && TB::BYTES == QB, "quarter size");
+    constexpr int MT = 8, NT = 4;
+    static_assert(!NORM || AKM, "row norms come from k-major A fragments");
+    __shared__ __attribute__((aligned(1024))) char lds[NQ * QB];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wm = wave >> 2, wn = wave & 3;
+    int tiles;
+    const int L = logical_block(epi, BM, tiles_m, tiles_n, true, tiles);
+    if (L < 0) return;
+    const int split = L / tiles, ti = L % tiles;
+    const int m0 = (ti / tiles_n) * BM, n0 = (ti % tiles_n) * BN;
+    const int kbeg = split * k_per_split;
+    const int kend = min(K, kbeg + k_per_split);
+    const int nk = kend > kbeg ? (kend - kbeg) / GEMM_BK : 0;          // the launcher guarantees whole K tiles
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float ss[2] = {0.f, 0.f};          // NORM: this lane's share of the squares of rows (2 wn + e) * 16 + (lane & 15)
+
+    const bf16_t* sa0[2]; const bf16_t* sa1[2]; const bf16_t* sb0[2]; const bf16_t* sb1[2];
+    dma_setup<128, AKM, NW>(A, lda, m0, M, wave, lane, sa0);
+    dma_setup<128, AKM, NW>(A, lda, m0 + 128, M, wave, lane, sa1);
+    // bf16 output: LDS row p of a wave's 64-column slab holds column sigma(p) of the slab (pp_sigma), which leaves
+    // every lane with 8 consecutive output columns per pair of accumulator fragments (16-byte stores straight from
+    // the registers, no staging through LDS).  fp32 output: identity (a fragment's 4 columns are 16 bytes already).
+    const bool perm = BKM && epi.out_bf16;
+    if (BKM) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int r, c;
+            TB::slot(wave * 2 + i, lane, r, c);
+            const int rr = perm ? (r & 64) + pp_sigma(r & 63) : r;
+            sb0[i] = B + (size_t)min(n0 + rr, N - 1) * ldb + c * 8;
+            sb1[i] = B + (size_t)min(n0 + 128 + rr, N - 1) * ldb + c * 8;
+        }
+    } else {
+        dma_setup<128, BKM, NW>(B, ldb, n0, N, wave, lane, sb0);
+        dma_setup<128, BKM, NW>(B, ldb, n0 + 128, N, wave, lane, sb1);
+    }
+    const size_t ka = AKM ? 1 : (size_t)lda, kb = BKM ? 1 : (size_t)ldb;
+
+    const int nq = 4 * nk;                                  // quarters of this workgroup's K range
+    // quarter q = 4 t + j goes to slot q % 10; J is the compile-time quarter kind
+    auto issue = [&](int q, auto J) {
+        if (q >= nq) return;
+#if defined(PP_PROBE) && PP_PROBE == 1
+        if (q >= 7) return;                                  // probe build: the K loop issues no DMA (timing only)
+#endif
+        char* dst = lds + (q % NQ) * QB;
+        const int k0 = kbeg + (q >> 2) * GEMM_BK;
+        constexpr int j = decltype(J)::value;
+        if (j == 0) dma_issue<128, BKM, NW>(sb0, k0 * kb, dst, wave);
+        else if (j == 1) dma_issue<128, BKM, NW>(sb1, k0 * kb, dst, wave);
+        else if (j == 2) dma_issue<128, AKM, NW>(sa0, k0 * ka, dst, wave);
+        else dma_issue<128, AKM, NW>(sa1, k0 * ka, dst, wave);
+    };
+    using J0 = std::integral_constant<int, 0>; using J1 = std::integral_constant<int, 1>;
+    using J2 = std::integral_constant<int, 2>; using J3 = std::integral_constant<int, 3>;
+
+#if defined(PP_PROBE) && PP_PROBE == 2
+    constexpr bool kCompute = false;                         // probe build: DMA and barriers only (timing only)
+#else
+    constexpr bool kCompute = true;
+#endif
+    bf16x8_t fa[2][4], fb0[2][2], fb1[2][2];
+    const int bc = (wn & 1) * 64;
+    auto sumsq = [&](const bf16x8_t& v, float s) {
+        s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(v, v, 0, 1), __builtin_shufflevector(v, v, 0, 1), s, false);
+        s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(v, v, 2, 3), __builtin_shufflevector(v, v, 2, 3), s, false);
+        s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(v, v, 4, 5), __builtin_shufflevector(v, v, 4, 5), s, false);
+        s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(v, v, 6, 7), __builtin_shufflevector(v, v, 6, 7), s, false);
+        return s;
+    };
+#define PP_MFMA(I0, FB, J0_)                                                                                    \
+    do {                                                                                                        \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
+        __builtin_amdgcn_s_setprio(1);                                                                          \
+        if (kCompute) _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                        \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                       \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                   \
+                    acc[(I0) + i][(J0_) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB[kk][j], fa[kk][i],    \
+                                                                                       acc[(I0) + i][(J0_) + j], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
+    } while (0)
+
+    // prologue: tile 0 and three quarters of tile 1
+    issue(0, J0{}); issue(1, J1{}); issue(2, J2{}); issue(3, J3{});
+    issue(4, J0{}); issue(5, J1{}); issue(6, J2{});
+    if (nk >= 2) { VMCNT_BARRIER(6); } else { VMCNT_BARRIER(0); }
+    if (wm == 1) __builtin_amdgcn_s_barrier();              // waves 4-7 run one barrier behind
+
+    for (int t = 0; t < nk; ++t) {
+        const int q0 = 4 * t;
+        const char* lb = lds + ((q0 + (wn >> 1)) % NQ) * QB;
+        const char* la = lds + ((q0 + 2 + wm) % NQ) * QB;
+        // ---- phase 0: B columns bc .. bc+31 and A rows 0 .. 63 of the wave's quarter -> acc[0..3][0..1]
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) if (kCompute) fb0[kk][j] = frag_read<128, BKM>(lb, bc + j * 16, kk, lane);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if (kCompute) fa[kk][i] = frag_read<128, AKM>(la, i * 16, kk, lane);
+        issue(q0 + 7, J3{});
+        __builtin_amdgcn_s_barrier();
+        PP_MFMA(0, fb0, 0);
+        if (NORM) {
+            if (wn == 0) { ss[0] = sumsq(fa[0][0], sumsq(fa[1][0], ss[0])); ss[1] = sumsq(fa[0][1], sumsq(fa[1][1], ss[1])); }
+            else if (wn == 1) { ss[0] = sumsq(fa[0][2], sumsq(fa[1][2], ss[0])); ss[1] = sumsq(fa[0][3], sumsq(fa[1][3], ss[1])); }
+        }
+        __builtin_amdgcn_s_barrier();
+        // ---- phase 1: B columns bc+32 .. bc+63 -> acc[0..3][2..3]
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) if (kCompute) fb1[kk][j] = frag_read<128, BKM>(lb, bc + 32 + j * 16, kk, lane);
+        issue(q0 + 8, J0{});
+        __builtin_amdgcn_s_barrier();
+        PP_MFMA(0, fb1, 2);
+        __builtin_amdgcn_s_barrier();
+        // ---- phase 2: A rows 64 .. 127 -> acc[4..7][2..3]
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if (kCompute) fa[kk][i] = frag_read<128, AKM>(la, 64 + i * 16, kk, lane);
+        issue(q0 + 9, J1{});
+        __builtin_amdgcn_s_barrier();
+        PP_MFMA(4, fb1, 2);
+        if (NORM) {
+            if (wn == 2) { ss[0] = sumsq(fa[0][0], sumsq(fa[1][0], ss[0])); ss[1] = sumsq(fa[0][1], sumsq(fa[1][1], ss[1])); }
+            else if (wn == 3) { ss[0] = sumsq(fa[0][2], sumsq(fa[1][2], ss[0])); ss[1] = sumsq(fa[0][3], sumsq(fa[1][3], ss[1])); }
+        }
+        __builtin_amdgcn_s_barrier();
+        // ---- phase 3: no reads (fb0 is still in registers) -> acc[4..7][0..1]; tile t+1 must have landed after it
+        issue(q0 + 10, J2{});
+        if (t + 2 < nk) { VMCNT_BARRIER(6); } else { VMCNT_BARRIER(0); }
+        PP_MFMA(4, fb0, 0);
+        __builtin_amdgcn_s_barrier();
+    }
+#undef PP_MFMA
+    if (wm == 0) __builtin_amdgcn_s_barrier();              // the barrier waves 4-7 took at the start
+#if defined(PP_PROBE) && PP_PROBE == 3
+    {                                                        // probe build: no output stores (timing only)
+        float s = 0.f;
+        for (int i = 0; i < MT; ++i) for (int j = 0; j < NT; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (s == 123.456f) ((float*)epi.out)[0] = s;
+        return;
+    }
+#endif
+    const float* rs_tile = nullptr;
+    if (NORM) {
+        VMCNT_BARRIER(0);    // every wave is done with the ring before its first bytes take the row scales
+        float* rs = reinterpret_cast<float*>(lds);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            float v = ss[e];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            const float inv = 1.0f / fmaxf(sqrtf(v), 1e-12f);
+            const int row = wm * 128 + (2 * wn + e) * 16 + (lane & 15);
+            if (lane < 16) {
+                rs[row] = inv;
+                if (n0 == 0 && m0 + row < M) epi.norm_out[m0 + row] = inv;
+            }
+        }
+        __syncthreads();
+        rs_tile = rs;
+    }
+    pp_store<NTS>(acc, epi, split, m0, wm * 128, n0 + wn * 64, M, N, lane, rs_tile, perm);
+}
+
 // ---- fp32 / any-stride VALU kernel -----------------------------------------------
 template <typename T, bool AKM, bool BKM>
 __global__ void __launch_bounds__(256)
@@ -843,6 +1143,7 @@ static inline int pick_tile(int M, int N, int K, int akm, int bkm, int engine) {
     if (engine == 6) return 512;                          // 256 x 256 tiles
     if (engine == 8) return 2048;                         // 256 x 256 tiles, ten-quarter ring
     if (engine == 9) return 4096;                         // same, all fragments of a K tile read before its MFMAs
+    if (engine == 10) return 8192;                        // 256 x 256 tiles, eight-phase schedule with staggered wave groups
     const long t128 = (long)ceil_div(M, 128) * ceil_div(N, 128);
     const long t256 = (long)ceil_div(M, 256) * ceil_div(N, 128);
     const long t512 = (long)ceil_div(M, 256) * ceil_div(N, 256);
@@ -864,18 +1165,49 @@ static inline int pick_tile(int M, int N, int K, int akm, int bkm, int engine) {
     return (M > 64 && N > 64 && t128 >= 40) ? 128 : 64;
 }
 
+// Streaming (non-temporal) output stores pay when the output is large and every row starts on a 128-byte line;
+// VQA_GEMM_NT=0 / 1 in the environment forces them off / on (A/B runs).
+static inline int want_nt_store(const Epi& epi, int M, int N, int splitk) {
+    static const int forced = [] { const char* e = getenv("VQA_GEMM_NT"); return e ? atoi(e) : -1; }();
+    const size_t esz = epi.out_bf16 ? 2 : 4;
+    const bool aligned = (((size_t)epi.ld * esz) % 128 == 0) && (((uintptr_t)epi.out) % 128 == 0) && ((epi.split_stride * 4) % 128 == 0);
+    if (!aligned) return 0;
+    if (forced >= 0) return forced;
+    return (size_t)M * N * esz * splitk >= ((size_t)96 << 20);
+}
+
+// VQA_GEMM_PP=0 in the environment keeps the ring kernels as the default 256 x 256 engine (A/B runs)
+static inline bool use_eight_phase() {
+    static const bool on = [] { const char* e = getenv("VQA_GEMM_PP"); return !e || atoi(e) != 0; }();
+    return on;
+}
+
 static int launch_bf16(const void* A, int lda, int akm, const void* B, int ldb, int bkm, int M, int N, int K,
                        int splitk, int engine, const Epi& epi, hipStream_t stream) {
     int kps = ceil_div(ceil_div(K, splitk), GEMM_BK) * GEMM_BK;
     // with a device-side row limit the live row count is unknown here: the tile is chosen for half the rows
     // when there are many row tiles (a packed batch of sequences), for all of them otherwise
     const int m_sched = (epi.m_limit && M >= 1024) ? M / 2 : M;
-    const int bm = pick_tile(m_sched, N, K, akm, bkm, engine);
+    int bm = pick_tile(m_sched, N, K, akm, bkm, engine);
+    if (engine == 0 && bm == 4096 && use_eight_phase()) bm = 8192;      // (falls back below when the shape does not fit)
     const bool big = bm == 128;
     const int bmr = bm >= 256 ? 256 : bm, bnr = bm >= 512 ? 256 : (bm == 256 ? 128 : bm);
     const int tm = ceil_div(M, bmr), tn = ceil_div(N, bnr);
     const unsigned grid = (unsigned)(tm * tn * splitk);
     const bf16_t* a = (const bf16_t*)A; const bf16_t* b = (const bf16_t*)B;
+    if (bm == 8192 && (kps % GEMM_BK || K % GEMM_BK || epi.m_limit || epi.k_limit || (epi.out_bf16 && !bkm))) return launch_bf16(A, lda, akm, B, ldb, bkm, M, N, K, splitk, 9, epi, stream);
+    if (bm == 8192) {
+        const bool nts = want_nt_store(epi, M, N, splitk);
+#define LAUNCHP(AK, BK_)                                                                                              \
+    do { if (nts) k_gemm_bf16_pp<AK, BK_, false, true><<<grid, 512, 0, stream>>>(a, lda, b, ldb, M, N, K, tm, tn, kps, epi); \
+         else k_gemm_bf16_pp<AK, BK_, false, false><<<grid, 512, 0, stream>>>(a, lda, b, ldb, M, N, K, tm, tn, kps, epi); } while (0)
+        if (akm && bkm) LAUNCHP(true, true);
+        else if (akm && !bkm) LAUNCHP(true, false);
+        else if (!akm && bkm) LAUNCHP(false, true);
+        else LAUNCHP(false, false);
+#undef LAUNCHP
+        return 0;
+    }
     if (bm == 2048 || bm == 4096) {
 #define LAUNCHR(AK, BK_)                                                                                              \
     do { if (bm == 2048) k_gemm_bf16_r10<AK, BK_, 0><<<grid, 512, 0, stream>>>(a, lda, b, ldb, M, N, K, tm, tn, kps, epi); \
@@ -1063,10 +1395,19 @@ int vqa_gemm_fused_rownorm(const void* A, int lda, const void* B, int ldb, void*
     VQA_REQUIRE(act == 0 || act == 1, "vqa_gemm_fused_rownorm: act must be 0 (none) or 1 (tanh)");
     VQA_REQUIRE(out_dtype == VQA_F32 || out_dtype == VQA_BF16, "vqa_gemm_fused_rownorm: out_dtype");
     const int bm = (dtype == VQA_BF16 && engine != 1) ? pick_tile(M, N, K, 1, 1, engine) : 0;
-    if (bm == 2048 || bm == 4096) {
+    if (bm == 2048 || bm == 4096 || bm == 8192) {
         Epi epi{C, ldc, out_dtype == VQA_BF16, 0, bias, nullptr, act, nullptr, nullptr, inv_norm};
         const int tm = ceil_div(M, 256), tn = ceil_div(N, 256);
         const int kps = ceil_div(K, GEMM_BK) * GEMM_BK;
+        if (use_eight_phase() && K % GEMM_BK == 0) {
+            if (want_nt_store(epi, M, N, 1))
+                k_gemm_bf16_pp<true, true, true, true><<<(unsigned)(tm * tn), 512, 0, stream>>>(
+                    (const bf16_t*)A, lda, (const bf16_t*)B, ldb, M, N, K, tm, tn, kps, epi);
+            else
+                k_gemm_bf16_pp<true, true, true, false><<<(unsigned)(tm * tn), 512, 0, stream>>>(
+                    (const bf16_t*)A, lda, (const bf16_t*)B, ldb, M, N, K, tm, tn, kps, epi);
+            return vqa_check_launch("vqa_gemm_fused_rownorm");
+        }
         k_gemm_bf16_r10<true, true, 0, true><<<(unsigned)(tm * tn), 512, 0, stream>>>(
             (const bf16_t*)A, lda, (const bf16_t*)B, ldb, M, N, K, tm, tn, kps, epi);
         return vqa_check_launch("vqa_gemm_fused_rownorm");

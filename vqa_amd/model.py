@@ -1037,14 +1037,20 @@ class VQAAttnModel(_VQAHeadModel):
     def _geometry(self, feats):
         return feats.shape[1]
 
+    def _ldA(self) -> int:
+        """Row pitch (elements) of the projected features P and of dP: rows start on 128-byte lines, so that the
+        projection's output stores and the attention kernels' row reads touch whole cache lines."""
+        return (self.A + 63) // 64 * 64 if self.pad_projection_rows else self.A
+
     def _visual_workspace(self, ws, z, B, R):
         tdt, f32 = self.compute_dtype, torch.float32
         H, A, Dv = self.Hq, self.A, self.Dv
-        ws.update({'inv_norm': z((B * R,), f32), 'dP': z((B * R, A), tdt),
+        ldA = self._ldA()
+        ws.update({'inv_norm': z((B * R,), f32), 'dP': z((B * R, ldA), tdt),
                    'dqa32': z((B, A), f32), 'dqaT': z((B, A), tdt), 'dwa_part': z((B, A), f32), 'dc_part': z((B,), f32),
                    'du32': z((B, H), f32), 'duT': z((B, H), tdt)})
         for k in range(self.hops):
-            ws[f'P{k}'] = z((B * R, A), tdt)
+            ws[f'P{k}'] = z((B * R, ldA), tdt)
             ws[f'qa{k}'] = z((B, A), f32)
             ws[f'p{k}'] = z((B, R), f32)
             ws[f'pooled{k}'] = z((B, Dv), tdt)
@@ -1057,6 +1063,7 @@ class VQAAttnModel(_VQAHeadModel):
     # launch that saves costs the kernel about as much as it gains (measured: 57 -> 60.7 us against a 4.8 us launch)
     attn_qa_from_slabs = False
     swap_big_wgrad = True    # dW_va is computed as its transpose (the faster operand orientation) and transposed by the reduce
+    pad_projection_rows = True
     fuse_row_norm = True     # the first hop's projection computes the region norms itself (one pass over the features less)
 
     def _visual_prologue(self, ws, feats, B):
@@ -1067,14 +1074,15 @@ class VQAAttnModel(_VQAHeadModel):
     def _visual_forward(self, ws, feats, B, seed, p):
         R = feats.shape[1]
         H, A, Dv, dt = self.Hq, self.A, self.Dv, self.dt
+        ldA = self._ldA()
         u32, uT = ws['q32'], ws['qT']
         for k in range(self.hops):
             pre = f'attention.{k}.'
             if k == 0 and self.fuse_row_norm:       # P = normalize(V) W_va^T + b, inv_norm written by the same launch
-                call('vqa_gemm_fused_rownorm', ptr(feats), Dv, ptr(self._w(pre + 'linear_va.weight')), Dv, ptr(ws[f'P{k}']), A,
+                call('vqa_gemm_fused_rownorm', ptr(feats), Dv, ptr(self._w(pre + 'linear_va.weight')), Dv, ptr(ws[f'P{k}']), ldA,
                      B * R, A, Dv, ptr(self._f32(pre + 'linear_va.bias')), ptr(ws['inv_norm']), 0, dt, dt, self.gemm_engine)
             else:
-                call('vqa_gemm_fused', ptr(feats), Dv, 1, ptr(self._w(pre + 'linear_va.weight')), Dv, 1, ptr(ws[f'P{k}']), A,
+                call('vqa_gemm_fused', ptr(feats), Dv, 1, ptr(self._w(pre + 'linear_va.weight')), Dv, 1, ptr(ws[f'P{k}']), ldA,
                      B * R, A, Dv, ptr(self._f32(pre + 'linear_va.bias')), ptr(ws['inv_norm']), 0, dt, dt, self.gemm_engine)
             early = k == 0 and 'qa0' in ws['early']
             if early and not self.attn_qa_from_slabs:
@@ -1087,13 +1095,13 @@ class VQAAttnModel(_VQAHeadModel):
             ev = self._event_pair('attn_fwd')
             if early:               # the kernel's prologue reduces the query projection's partial sums (+ bias) into qa0
                 slab, sk, st = ws['early']['qa0']
-                call('vqa_attn_fwd_qslabs', ptr(ws[f'P{k}']), A, ptr(feats), Dv, slab, sk, st,
+                call('vqa_attn_fwd_qslabs', ptr(ws[f'P{k}']), ldA, ptr(feats), Dv, slab, sk, st,
                      ptr(self._f32(pre + 'linear_qa.bias')), ptr(ws['qa0']), A,
                      ptr(self._f32(pre + 'linear_a.weight')), ptr(self._f32(pre + 'linear_a.bias')), ptr(ws['inv_norm']),
                      ptr(ws[f'p{k}']), ptr(ws[f'pooled{k}']), None, Dv, B, R, A, Dv, dt,
                      ptr(ws['pooled_d']) if k + 1 == self.hops else None, seed, p)
             else:
-                call('vqa_attn_fwd', ptr(ws[f'P{k}']), A, ptr(feats), Dv, ptr(ws[f'qa{k}']), A,
+                call('vqa_attn_fwd', ptr(ws[f'P{k}']), ldA, ptr(feats), Dv, ptr(ws[f'qa{k}']), A,
                      ptr(self._f32(pre + 'linear_a.weight')), ptr(self._f32(pre + 'linear_a.bias')), ptr(ws['inv_norm']),
                      ptr(ws[f'p{k}']), ptr(ws[f'pooled{k}']), None, Dv, B, R, A, Dv, dt,
                      ptr(ws['pooled_d']) if k + 1 == self.hops else None, seed, p)   # dropoutV fused into the last hop
@@ -1107,6 +1115,7 @@ class VQAAttnModel(_VQAHeadModel):
     def _visual_backward(self, ws, feats, B):
         R = feats.shape[1]
         H, A, Dv, dt = self.Hq, self.A, self.Dv, self.dt
+        ldA = self._ldA()
         g = self._g
         # attention hops, last to first
         du_carry = None
@@ -1116,14 +1125,14 @@ class VQAAttnModel(_VQAHeadModel):
             src = ws.get('dpool_src') if k + 1 == self.hops else None
             if src is not None:
                 slab, sk, st, dseed, dp = src
-                call('vqa_attn_bwd_dslabs', ptr(ws[f'P{k}']), A, ptr(feats), Dv, ptr(ws[f'qa{k}']), A,
+                call('vqa_attn_bwd_dslabs', ptr(ws[f'P{k}']), ldA, ptr(feats), Dv, ptr(ws[f'qa{k}']), A,
                      ptr(self._f32(pre + 'linear_a.weight')), ptr(ws['inv_norm']), ptr(ws[f'p{k}']), slab, sk, st, dseed, dp,
-                     ptr(ws['d_pooled']), Dv, ptr(ws['dP']), A, ptr(ws['dqa32']), ptr(ws['dqaT']), A, ptr(ws['dwa_part']),
+                     ptr(ws['d_pooled']), Dv, ptr(ws['dP']), ldA, ptr(ws['dqa32']), ptr(ws['dqaT']), A, ptr(ws['dwa_part']),
                      ptr(ws['dc_part']), B, R, A, Dv, dt)
             else:
-                call('vqa_attn_bwd', ptr(ws[f'P{k}']), A, ptr(feats), Dv, ptr(ws[f'qa{k}']), A,
+                call('vqa_attn_bwd', ptr(ws[f'P{k}']), ldA, ptr(feats), Dv, ptr(ws[f'qa{k}']), A,
                      ptr(self._f32(pre + 'linear_a.weight')), ptr(ws['inv_norm']), ptr(ws[f'p{k}']), ptr(ws['d_pooled']), Dv,
-                     ptr(ws['dP']), A, ptr(ws['dqa32']), ptr(ws['dqaT']), A, ptr(ws['dwa_part']), ptr(ws['dc_part']),
+                     ptr(ws['dP']), ldA, ptr(ws['dqa32']), ptr(ws['dqaT']), A, ptr(ws['dwa_part']), ptr(ws['dc_part']),
                      B, R, A, Dv, dt)
             # the hop's small gradients in one launch: w_a, its offset c, and the two biases that share d(P + qa)
             self._wgrad_grouped([(ws['dqaT'], A, uT, H, pre + 'linear_qa.weight', A, H, B)],
@@ -1145,7 +1154,7 @@ class VQAAttnModel(_VQAHeadModel):
                 if du_carry is not None:
                     self._add_dq(ws, B, du_carry, 1, 0)
             self._bucket_done(pre + 'linear_va.bias')
-            self._wgrad(ws['dP'], A, feats, Dv, pre + 'linear_va.weight', A, Dv, B * R, swapped=self.swap_big_wgrad)
+            self._wgrad(ws['dP'], ldA, feats, Dv, pre + 'linear_va.weight', A, Dv, B * R, swapped=self.swap_big_wgrad)
             self._bucket_done(pre + 'linear_va.weight')
             if k > 0:
                 slab, sk, st = self._gemm_slabs(ws['duT'], H, 1, self._w(ppre + 'linear_u.weight'), Dv, 0, B, Dv, H)
