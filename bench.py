@@ -83,6 +83,7 @@ def main():
                     help='A/B: gather embeddings and run the LSTM input projection every step instead of the per-token table')
     ap.add_argument('--no-fold-first-step', action='store_true', help='A/B: run the recurrent product of step 1 as a GEMM')
     ap.add_argument('--no-swap-wgrad', action='store_true', help='A/B: dW_va in the nn.Linear orientation')
+    ap.add_argument('--no-overlap-encoder', action='store_true', help='A/B: question encoder on the main stream, before the image side')
     ap.add_argument('--no-pad-rows', action='store_true', help='A/B: projected features P / dP with unpadded 2400-byte rows')
     ap.add_argument('--rccl-single', action='store_true',
                     help='N=1 only: run the bucketed all-reduce path over a one-rank RCCL group (its cost without peers)')
@@ -114,6 +115,8 @@ def main():
         model.fold_first_step = False
     if args.no_swap_wgrad:
         model.swap_big_wgrad = False
+    if args.no_overlap_encoder:
+        model.overlap_encoder = False
     if args.no_pad_rows:
         model.pad_projection_rows = False
     reducer = GradReducer(force=args.rccl_single) if (world > 1 or args.rccl_single) else None

@@ -26,11 +26,15 @@ def run_fused(name, M, N, K, engines, ldc=None):
         us = timeit(lambda: call('vqa_gemm_fused', ptr(A), K, 1, ptr(Bm), K, 1, ptr(C), ldc, M, N, K, ptr(bias), ptr(rs), 0, 1, 1, eng))
         print(f'{name:12s} fused bf16 out ldc={ldc} M={M:6d} N={N:5d} K={K:6d} engine={eng:2d}: {us:8.1f} us  {2.0 * M * N * K / us / 1e6:7.1f} TF')
 
-def run(name, M, N, K, akm, bkm, variants):
+def run(name, M, N, K, akm, bkm, variants, ldb=None):
     dt = torch.bfloat16
     A = (torch.randn((M, K) if akm else (K, M), device='cuda') * 0.5).to(dt)
-    Bm = (torch.randn((N, K) if bkm else (K, N), device='cuda') * 0.5).to(dt)
-    lda = K if akm else M; ldb = K if bkm else N
+    if ldb and not bkm:
+        Bm = (torch.randn((K, ldb), device='cuda') * 0.5).to(dt)
+    else:
+        Bm = (torch.randn((N, K) if bkm else (K, N), device='cuda') * 0.5).to(dt)
+        ldb = K if bkm else N
+    lda = K if akm else M
     slab = torch.empty(max(v[1] for v in variants) * M * N, device='cuda', dtype=torch.float32)
     for eng, sk in variants:
         us = timeit(lambda: call('vqa_gemm_slabs', ptr(A), lda, int(akm), ptr(Bm), ldb, int(bkm), ptr(slab), M * N, N, M, N, K, sk, 1, eng))
@@ -58,6 +62,10 @@ if __name__ == '__main__':
             run('K4 fwd NT', 50176, 1200, 2048, True, True, [(10, 1)])
             run('sq4k', 4096, 4096, 4096, True, True, [(10, 1)])
             run('square', 8192, 8192, 8192, True, True, [(10, 1)])
+    elif which == 'wg':
+        for _ in range(3):
+            run('wgrad TN swapped', 2048, 1200, 50176, False, False, [(6, 6), (10, 6), (10, 5), (10, 7)])
+            run('wgrad TN sw ld1280', 2048, 1200, 50176, False, False, [(6, 6), (10, 6)], ldb=1280)
     elif which == 'probe':
         for _ in range(2):
             run('K4 fwd NT', 50176, 1200, 2048, True, True, [(9, 1)])

@@ -659,6 +659,19 @@ class _VQAHeadModel(nn.Module):
                      seeds[li], self.seq2vec_dropout, dt)
         return ws['q32']
 
+    overlap_encoder = True        # frozen question encoder on a second stream beside the image side (see _forward_impl)
+
+    def _side_stream(self, device):
+        st = getattr(self, '_side', None)
+        if st is None or st.device != device:
+            self._side = st = torch.cuda.Stream(device=device)
+            self._enc_done = torch.cuda.Event()
+        return st
+
+    def _visual_early(self, ws, feats, B):
+        """Question-independent part of the visual forward (runs beside the question encoder); the default is none."""
+        ws['visual_early_done'] = False
+
     def _enc_workspace(self, B, L, device):
         """Question-encoder buffers alone (encode_question called outside a forward)."""
         key = ('enc', B, L, str(device))
@@ -704,10 +717,27 @@ class _VQAHeadModel(nn.Module):
         if self.train_encoder:
             self._finish_pending()               # the deferred bucket holds the encoder's own weights
             self._frozen_key = None              # they change every step: refresh the operand copies
-        self.encode_question(tokens, ws, seeds[4:6], q_drop=(ws['q_d'], seeds[1], p))
+        # A frozen question encoder depends on nothing the image side produces (and on no trainable weight): it runs
+        # on a second stream beside the image side's question-independent work (_visual_early: the region projection
+        # of the attention model) and is joined before the first kernel that reads the question vector.  Its chain of
+        # short dependent launches fills the gaps of the one long MFMA-bound product instead of preceding it.
+        side = self._side_stream(dev) if (self.overlap_encoder and not self.train_encoder) else None
+        if side is not None:
+            main = torch.cuda.current_stream(dev)
+            self._refresh_frozen(dev)            # (allocations and table builds stay on the main stream)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                self.encode_question(tokens, ws, seeds[4:6], q_drop=(ws['q_d'], seeds[1], p))
+                self._enc_done.record(side)
+            _lib.bind_stream()
+        else:
+            self.encode_question(tokens, ws, seeds[4:6], q_drop=(ws['q_d'], seeds[1], p))
         self._visual_prologue(ws, feats, B)
         self._finish_pending()
         self._refresh_shadow()
+        self._visual_early(ws, feats, B)
+        if side is not None:
+            main.wait_event(self._enc_done)
         if self.seq2vec.arch == '2-lstm':       # (the single-layer encoder's cell kernel wrote q_d already)
             call('vqa_dropout', ptr(ws['qT']), H, ptr(ws['q_d']), H, B, H, seeds[1], p, dt)
         self._launch_early(ws, B)                                  # question-side products of the head, one launch
@@ -1071,6 +1101,25 @@ class VQAAttnModel(_VQAHeadModel):
         if not self.fuse_row_norm:
             call('vqa_inv_norm', ptr(feats), ptr(ws['inv_norm']), B * R, Dv, Dv, self.dt)
 
+    def _project(self, ws, feats, B, k):
+        """P^k = normalize(V) W_va^k^T + b (B R, A); hop 0 with fuse_row_norm also writes inv_norm."""
+        R = feats.shape[1]
+        A, Dv, dt = self.A, self.Dv, self.dt
+        ldA = self._ldA()
+        pre = f'attention.{k}.'
+        if k == 0 and self.fuse_row_norm:       # inv_norm written by the same launch
+            call('vqa_gemm_fused_rownorm', ptr(feats), Dv, ptr(self._w(pre + 'linear_va.weight')), Dv, ptr(ws[f'P{k}']), ldA,
+                 B * R, A, Dv, ptr(self._f32(pre + 'linear_va.bias')), ptr(ws['inv_norm']), 0, dt, dt, self.gemm_engine)
+        else:
+            call('vqa_gemm_fused', ptr(feats), Dv, 1, ptr(self._w(pre + 'linear_va.weight')), Dv, 1, ptr(ws[f'P{k}']), ldA,
+                 B * R, A, Dv, ptr(self._f32(pre + 'linear_va.bias')), ptr(ws['inv_norm']), 0, dt, dt, self.gemm_engine)
+
+    def _visual_early(self, ws, feats, B):
+        # every hop's region projection reads the features and its own weights only: none waits for the question
+        for k in range(self.hops):
+            self._project(ws, feats, B, k)
+        ws['visual_early_done'] = True
+
     def _visual_forward(self, ws, feats, B, seed, p):
         R = feats.shape[1]
         H, A, Dv, dt = self.Hq, self.A, self.Dv, self.dt
@@ -1078,12 +1127,8 @@ class VQAAttnModel(_VQAHeadModel):
         u32, uT = ws['q32'], ws['qT']
         for k in range(self.hops):
             pre = f'attention.{k}.'
-            if k == 0 and self.fuse_row_norm:       # P = normalize(V) W_va^T + b, inv_norm written by the same launch
-                call('vqa_gemm_fused_rownorm', ptr(feats), Dv, ptr(self._w(pre + 'linear_va.weight')), Dv, ptr(ws[f'P{k}']), ldA,
-                     B * R, A, Dv, ptr(self._f32(pre + 'linear_va.bias')), ptr(ws['inv_norm']), 0, dt, dt, self.gemm_engine)
-            else:
-                call('vqa_gemm_fused', ptr(feats), Dv, 1, ptr(self._w(pre + 'linear_va.weight')), Dv, 1, ptr(ws[f'P{k}']), ldA,
-                     B * R, A, Dv, ptr(self._f32(pre + 'linear_va.bias')), ptr(ws['inv_norm']), 0, dt, dt, self.gemm_engine)
+            if not ws.get('visual_early_done'):
+                self._project(ws, feats, B, k)
             early = k == 0 and 'qa0' in ws['early']
             if early and not self.attn_qa_from_slabs:
                 slab, sk, st = ws['early']['qa0']
