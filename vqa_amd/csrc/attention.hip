@@ -768,7 +768,9 @@ k_attn_bwd_pipe(const bf16_t* __restrict__ P, int ldP, const bf16_t* __restrict_
             u16x8 ov;
 #pragma unroll
             for (int e = 0; e < 8; ++e) ov[e] = f32_to_bf16(o[e]);
-            __builtin_nontemporal_store(ov, reinterpret_cast<u16x8*>(colD + (size_t)r * ld_dP));
+            // (a cached store: the weight-gradient product that follows reads dP, and what of it is still in the
+            //  Infinity Cache arrives sooner than from HBM: -4 us per step against a non-temporal store)
+            *reinterpret_cast<u16x8*>(colD + (size_t)r * ld_dP) = ov;
         };
         // two batches of 4 rows in flight: the next batch is requested before the current one is consumed
         // (row indices clamped, so every load is unconditional; rows past R are not consumed)

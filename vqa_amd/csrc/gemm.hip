@@ -799,6 +799,48 @@ k_gemm_bf16_r10(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict_
 // quarters stay in flight across the tile boundary (one counted wait per K tile, never a drain), and a slot is
 // refilled no sooner than two phases after its last fragment read.
 // Every wave executes the same number of barriers: 1 + 8 nk + 1 + 1.
+// One 16 KiB quarter = two LDS-DMA instructions per wave.  In the m-major image a wave's second instruction covers the
+// four k-rows after the first one's with the same swizzle, so its source is the first one's plus 4 rows: one pointer
+// per quarter is kept in registers instead of two.
+template <bool KM>
+__device__ __forceinline__ void pp_issue_quarter(const bf16_t* const (&src)[2], size_t koff, char* lds, int wave, int ld) {
+    typedef __attribute__((address_space(1))) const void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    if (KM) {
+        __builtin_amdgcn_global_load_lds((gptr_t)(src[0] + koff), (lptr_t)(lds + (wave * 2) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(src[1] + koff), (lptr_t)(lds + (wave * 2 + 1) * 1024), 16, 0, 0);
+    } else {
+        const bf16_t* p = src[0] + koff;
+        __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(lds + (wave * 2) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(p + 4 * (size_t)ld), (lptr_t)(lds + (wave * 2 + 1) * 1024), 16, 0, 0);
+    }
+}
+
+// Fragment of an m-major 128-wide quarter ([64 k-rows][128] bf16, chunk ^= swizzle(k-row)) with the address arithmetic
+// taken out of the K loop: the byte offset of the lane's first transposed 8-byte read is
+//     L + ((2 r0) ^ X) + 8192 kk (+ 1024 for the k-rows 4 further)
+// with L (k-row and position inside the 32-byte group) and X (the swizzle, a multiple of 32) per-lane constants and
+// r0 the fragment's first tile row: one xor and one add per fragment, the rest are instruction offsets.  The
+// waves of a SIMD share its vector issue with the partner's MFMAs, so every VALU instruction of the read phase counts.
+struct PpMLane { unsigned L, X; };
+__device__ __forceinline__ PpMLane pp_m_lane(int lane) {
+    const int g = lane >> 4, li = lane & 15;
+    const int krow = 8 * g + (li >> 2);
+    PpMLane r;
+    r.L = (unsigned)(krow * 256 + ((li & 3) >> 1) * 16 + (li & 1) * 8);
+    r.X = (unsigned)(Tile<128, false>::swz(krow) << 4);
+    return r;
+}
+__device__ __forceinline__ bf16x8_t pp_frag_m(unsigned base_plus_L, unsigned X, int r0, int kk) {
+    typedef s16x4_t __attribute__((address_space(3))) * lds_p;
+    const unsigned a = base_plus_L + (((unsigned)(2 * r0)) ^ X);
+    const lds_p p = (lds_p)(size_t)a;
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(p + kk * 1024);
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(p + kk * 1024 + 128);
+    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+
 // Column permutation of the eight-phase kernel's bf16 epilogue: with the B fragment as the first MFMA operand a lane
 // (g = lane >> 4, c = lane & 15) ends up with C[row 16 i + c][slab position 16 j + 4 g + r] in acc[i][j][r]; slab
 // position p holds output column sigma(p) = 32 (j >> 1) + 8 g + 4 (j & 1) + r, so fragments j = 0, 1 (and 2, 3) of a
@@ -956,10 +998,10 @@ k_gemm_bf16_pp(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__
         char* dst = lds + (q % NQ) * QB;
         const int k0 = kbeg + (q >> 2) * GEMM_BK;
         constexpr int j = decltype(J)::value;
-        if (j == 0) dma_issue<128, BKM, NW>(sb0, k0 * kb, dst, wave);
-        else if (j == 1) dma_issue<128, BKM, NW>(sb1, k0 * kb, dst, wave);
-        else if (j == 2) dma_issue<128, AKM, NW>(sa0, k0 * ka, dst, wave);
-        else dma_issue<128, AKM, NW>(sa1, k0 * ka, dst, wave);
+        if (j == 0) pp_issue_quarter<BKM>(sb0, k0 * kb, dst, wave, ldb);
+        else if (j == 1) pp_issue_quarter<BKM>(sb1, k0 * kb, dst, wave, ldb);
+        else if (j == 2) pp_issue_quarter<AKM>(sa0, k0 * ka, dst, wave, lda);
+        else pp_issue_quarter<AKM>(sa1, k0 * ka, dst, wave, lda);
     };
     using J0 = std::integral_constant<int, 0>; using J1 = std::integral_constant<int, 1>;
     using J2 = std::integral_constant<int, 2>; using J3 = std::integral_constant<int, 3>;
@@ -971,6 +1013,17 @@ k_gemm_bf16_pp(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__
 #endif
     bf16x8_t fa[2][4], fb0[2][2], fb1[2][2];
     const int bc = (wn & 1) * 64;
+    const PpMLane ml = pp_m_lane(lane);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+    // fragment of the 16 tile rows from r0 of the quarter at `q` (generic pointer) / `qu` (LDS byte address + ml.L)
+    auto read_a = [&](const char* q, unsigned qu, int r0, int kk) -> bf16x8_t {
+        if (AKM) return frag_read<128, true>(q, r0, kk, lane);
+        return pp_frag_m(qu, ml.X, r0, kk);
+    };
+    auto read_b = [&](const char* q, unsigned qu, int r0, int kk) -> bf16x8_t {
+        if (BKM) return frag_read<128, true>(q, r0, kk, lane);
+        return pp_frag_m(qu, ml.X, r0, kk);
+    };
     auto sumsq = [&](const bf16x8_t& v, float s) {
         s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(v, v, 0, 1), __builtin_shufflevector(v, v, 0, 1), s, false);
         s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(v, v, 2, 3), __builtin_shufflevector(v, v, 2, 3), s, false);
@@ -1000,18 +1053,20 @@ k_gemm_bf16_pp(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__
 
     for (int t = 0; t < nk; ++t) {
         const int q0 = 4 * t;
-        const char* lb = lds + ((q0 + (wn >> 1)) % NQ) * QB;
-        const char* la = lds + ((q0 + 2 + wm) % NQ) * QB;
+        const int sb_ = (q0 + (wn >> 1)) % NQ, sa_ = (q0 + 2 + wm) % NQ;
+        const char* lb = lds + sb_ * QB;
+        const char* la = lds + sa_ * QB;
+        const unsigned lbu = lds0 + sb_ * QB + ml.L, lau = lds0 + sa_ * QB + ml.L;
         // ---- phase 0: B columns bc .. bc+31 and A rows 0 .. 63 of the wave's quarter -> acc[0..3][0..1]
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) if (kCompute) fb0[kk][j] = frag_read<128, BKM>(lb, bc + j * 16, kk, lane);
+            for (int j = 0; j < 2; ++j) if (kCompute) fb0[kk][j] = read_b(lb, lbu, bc + j * 16, kk);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) if (kCompute) fa[kk][i] = frag_read<128, AKM>(la, i * 16, kk, lane);
+            for (int i = 0; i < 4; ++i) if (kCompute) fa[kk][i] = read_a(la, lau, i * 16, kk);
         issue(q0 + 7, J3{});
         __builtin_amdgcn_s_barrier();
         PP_MFMA(0, fb0, 0);
@@ -1024,7 +1079,7 @@ k_gemm_bf16_pp(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) if (kCompute) fb1[kk][j] = frag_read<128, BKM>(lb, bc + 32 + j * 16, kk, lane);
+            for (int j = 0; j < 2; ++j) if (kCompute) fb1[kk][j] = read_b(lb, lbu, bc + 32 + j * 16, kk);
         issue(q0 + 8, J0{});
         __builtin_amdgcn_s_barrier();
         PP_MFMA(0, fb1, 2);
@@ -1033,7 +1088,7 @@ k_gemm_bf16_pp(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) if (kCompute) fa[kk][i] = frag_read<128, AKM>(la, 64 + i * 16, kk, lane);
+            for (int i = 0; i < 4; ++i) if (kCompute) fa[kk][i] = read_a(la, lau, 64 + i * 16, kk);
         issue(q0 + 9, J1{});
         __builtin_amdgcn_s_barrier();
         PP_MFMA(4, fb1, 2);
@@ -1189,13 +1244,13 @@ static int launch_bf16(const void* A, int lda, int akm, const void* B, int ldb, 
     // when there are many row tiles (a packed batch of sequences), for all of them otherwise
     const int m_sched = (epi.m_limit && M >= 1024) ? M / 2 : M;
     int bm = pick_tile(m_sched, N, K, akm, bkm, engine);
-    if (engine == 0 && bm == 4096 && use_eight_phase()) bm = 8192;      // (falls back below when the shape does not fit)
+    if (engine == 0 && (bm == 4096 || bm == 512) && use_eight_phase()) bm = 8192;   // (falls back below when the shape does not fit)
     const bool big = bm == 128;
     const int bmr = bm >= 256 ? 256 : bm, bnr = bm >= 512 ? 256 : (bm == 256 ? 128 : bm);
     const int tm = ceil_div(M, bmr), tn = ceil_div(N, bnr);
     const unsigned grid = (unsigned)(tm * tn * splitk);
     const bf16_t* a = (const bf16_t*)A; const bf16_t* b = (const bf16_t*)B;
-    if (bm == 8192 && (kps % GEMM_BK || K % GEMM_BK || epi.m_limit || epi.k_limit || (epi.out_bf16 && !bkm))) return launch_bf16(A, lda, akm, B, ldb, bkm, M, N, K, splitk, 9, epi, stream);
+    if (bm == 8192 && (kps % GEMM_BK || K % GEMM_BK || epi.m_limit || epi.k_limit || (epi.out_bf16 && !bkm))) return launch_bf16(A, lda, akm, B, ldb, bkm, M, N, K, splitk, (akm && bkm) ? 9 : 6, epi, stream);
     if (bm == 8192) {
         const bool nts = want_nt_store(epi, M, N, splitk);
 #define LAUNCHP(AK, BK_)                                                                                              \
