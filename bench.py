@@ -24,6 +24,7 @@ sys.path.insert(0, ROOT)
 
 METRIC = 'train samples/sec (whole node) at 1/2/4/8 MI355X; fused-attn HBM GB/s % peak'
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak
+MFMA_PEAK_TFLOPS = 2500.0    # MI355X dense bf16 MFMA peak
 
 
 def synth_batches(n, B, R, Dv, L, Vq, C, device, seed, dtype):
@@ -58,15 +59,17 @@ def cpu_baseline(B, R, Dv, L, Vq, C, threads):
         for k in names:
             vqa_ref.adam_step(p[k], g[k], m[k], v[k], i, 1e-5)
 
-    step(1)                                   # warm-up (allocator, thread pool)
-    t0 = time.perf_counter()
-    n = 6
+    for i in range(3):                        # warm-up (allocator, thread pool)
+        step(1 + i)
+    n, times = 10, []
     for i in range(n):
-        step(2 + i)
-    dt = (time.perf_counter() - t0) / n
+        t0 = time.perf_counter()
+        step(4 + i)
+        times.append(time.perf_counter() - t0)
+    dt = sorted(times)[n // 2]
     return {'value': Bs / dt, 'unit': 'samples/s', 'cores': threads, 'kind': 'port',
-            'sample': f'{n} timed steps (fwd+CE+bwd+Adam, fp32, dropout on) of the CPU oracle at the per-GPU '
-                      f'batch {Bs}, same model widths and input shapes, after 1 warm-up step'}
+            'sample': f'median of {n} timed steps (fwd+CE+bwd+Adam, fp32, dropout on) of the CPU oracle at the per-GPU '
+                      f'batch {Bs}, same model widths and input shapes, after 3 warm-up steps'}
 
 
 def main():
@@ -78,12 +81,13 @@ def main():
     ap.add_argument('--regions', type=int, default=196)
     ap.add_argument('--hops', type=int, default=1)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-unfolded', action='store_true', help='skip the second timed loop (question encoder with nothing tabulated)')
     ap.add_argument('--no-fuse-norm', action='store_true', help='A/B: separate row-norm pass before the image projection')
     ap.add_argument('--no-fold-embedding', action='store_true',
                     help='A/B: gather embeddings and run the LSTM input projection every step instead of the per-token table')
     ap.add_argument('--no-fold-first-step', action='store_true', help='A/B: run the recurrent product of step 1 as a GEMM')
     ap.add_argument('--no-swap-wgrad', action='store_true', help='A/B: dW_va in the nn.Linear orientation')
-    ap.add_argument('--no-overlap-encoder', action='store_true', help='A/B: question encoder on the main stream, before the image side')
+    ap.add_argument('--overlap-encoder', action='store_true', help='A/B: frozen question encoder on a second stream beside the region projection')
     ap.add_argument('--no-pad-rows', action='store_true', help='A/B: projected features P / dP with unpadded 2400-byte rows')
     ap.add_argument('--rccl-single', action='store_true',
                     help='N=1 only: run the bucketed all-reduce path over a one-rank RCCL group (its cost without peers)')
@@ -107,6 +111,7 @@ def main():
     B, R, Dv, L, Vq, C = args.batch, args.regions, 2048, 14, 10000, 3000
     model = VQAAttnModel(['w'] * Vq, ['a'] * C, None, dtype=torch.bfloat16, hops=args.hops, seed=0).to(dev)
     model.train()
+    model.dropout_rank = rank          # same weights on every rank, different dropout masks
     if args.no_fuse_norm:
         model.fuse_row_norm = False
     if args.no_fold_embedding:
@@ -115,8 +120,8 @@ def main():
         model.fold_first_step = False
     if args.no_swap_wgrad:
         model.swap_big_wgrad = False
-    if args.no_overlap_encoder:
-        model.overlap_encoder = False
+    if args.overlap_encoder:
+        model.overlap_encoder = True
     if args.no_pad_rows:
         model.pad_projection_rows = False
     reducer = GradReducer(force=args.rccl_single) if (world > 1 or args.rccl_single) else None
@@ -136,6 +141,8 @@ def main():
     torch.cuda.synchronize()
     model.kernel_events = {}
     model.kernel_event_stride = args.event_stride
+    if reducer is not None:
+        reducer.timing = {}
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = step(args.warmup + i)
@@ -145,14 +152,58 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    my_elapsed_local = elapsed
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
 
+    diag = None
+    try:                                   # diagnostics must never cost the run its result line
+        if world > 1:
+            # what the first multi-GPU run needs to explain itself: who took part, what was reduced, what the compute
+            # stream waited for, how uneven the ranks were
+            props = torch.cuda.get_device_properties(dev)
+            me = {'rank': rank, 'local_rank': local, 'device': torch.cuda.current_device(), 'name': props.name,
+                  'uuid': str(getattr(props, 'uuid', '')), 'ms_per_step': my_elapsed_local / args.steps * 1e3}
+            everyone = [None] * world
+            dist.all_gather_object(everyone, me)
+            diag = {'rccl_ranks': everyone,
+                    'ms_per_step_min': min(e['ms_per_step'] for e in everyone),
+                    'ms_per_step_max': max(e['ms_per_step'] for e in everyone)}
+        if reducer is not None and reducer.timing:
+            launches = reducer.timing.get('launch', [])
+            waits = reducer.timing.get('wait', [])
+            per_step = max(len(launches) // max(args.steps, 1), 1)
+            exposed = sum(a.elapsed_time(b) for a, b in waits) / max(args.steps, 1)
+            comm = {'collectives_per_step': per_step,
+                    'allreduce_bytes_per_step': sum(nby for nby, _ in launches) // max(args.steps, 1),
+                    'bytes_of_each_collective': [nby for nby, _ in launches[:per_step]],
+                    'waits_per_step': len(waits) / max(args.steps, 1),
+                    'exposed_wait_ms_per_step': exposed,
+                    'note': 'exposed_wait = HIP-event time the compute stream spent in cross-stream waits for the '
+                            'collectives (everything else of them ran under backward / the next forward)'}
+            # span of a collective: from its launch to the end of the first wait recorded after it (an upper bound:
+            # the wait sits one step later in the fully deferred schedule)
+            spans = []
+            wi = 0
+            for _nby, ev in launches[:-per_step] if len(launches) > per_step else []:
+                while wi < len(waits) and ev.elapsed_time(waits[wi][1]) <= 0:
+                    wi += 1
+                if wi < len(waits):
+                    spans.append(ev.elapsed_time(waits[wi][1]))
+            if spans:
+                comm['launch_to_wait_end_ms_avg'] = sum(spans) / len(spans)
+                comm['launch_to_wait_end_ms_max'] = max(spans)
+            diag = dict(diag or {}, communication=comm)
+    except Exception as exc:               # noqa: BLE001
+        diag = dict(diag or {}, diagnostics_error=repr(exc))
+
     if rank == 0:
-        ev = model.kernel_events.get('attn_fwd', [])
-        k6_ms = sum(s.elapsed_time(e) for s, e in ev) / max(len(ev), 1)
+        def avg_ms(name):
+            ev = model.kernel_events.get(name, [])
+            return (sum(a.elapsed_time(b) for a, b in ev) / len(ev), len(ev)) if ev else (0.0, 0)
+        k6_ms, k6_n = avg_ms('attn_fwd')
         # algorithmic bytes of the fused attention forward per sample and hop (bf16):
         # P (R*A) + V (R*Dv) + qa (A) + pooled (Dv) at 2 B, inv_norm (R) + p (R) at 4 B
         A = model.A
@@ -162,6 +213,16 @@ def main():
         tpath = os.path.join(ROOT, 'profiles', 'attn_fwd_traffic.json')
         if os.path.exists(tpath) and B == 256 and R == 196 and args.hops == 1:
             traffic = json.load(open(tpath)).get('hbm_bytes_per_launch')
+        # the two MFMA-bound products: region projection (forward) and its weight gradient, 2 B R Dv A flop each
+        gemm_flop = 2.0 * B * R * Dv * A
+        gemms = {}
+        for key, label in (('proj:0', 'image projection P = normalize(V) W_va^T + b (k_gemm_bf16_pp, row norms fused)'),
+                           ('wgrad:attention.0.linear_va.weight', 'weight gradient dW_va = dP^T V (k_gemm_bf16_pp, split-K partial sums)')):
+            ms, n = avg_ms(key)
+            if n:
+                tf = gemm_flop / (ms * 1e-3) / 1e12
+                gemms[key.split(':')[0]] = {'kernel': label, 'flop_per_launch': gemm_flop, 'avg_launch_ms': ms, 'timed_launches': n,
+                                            'achieved': tf, 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': tf / MFMA_PEAK_TFLOPS}
         out = {
             'metric': METRIC, 'value': world * B * args.steps / elapsed, 'unit': 'samples/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -178,10 +239,46 @@ def main():
                                               and model.fold_first_step else '')},
             'roofline': {'bound': 'hbm', 'kernel': 'k_attn_fwd_online (fused attention forward)', 'achieved': achieved,
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                         'avg_launch_ms': k6_ms, 'timed_launches': len(ev),
+                         'avg_launch_ms': k6_ms, 'timed_launches': k6_n,
                          'algorithmic_bytes_per_launch': k6_bytes},
+            'roofline_gemm': dict(gemms, bound='mfma', note='HIP events on the launch stream inside the timed region; the '
+                                  'question encoder runs on a second stream beside the projection, so its span includes '
+                                  'the CU time the encoder kernels took'),
             'loss': float(loss),
         }
+        if diag:
+            out['multi_gpu'] = diag
+    # the same step with nothing of the frozen question encoder tabulated (embedding gather + every LSTM product
+    # computed each step): a second, shorter timed loop
+    if not args.no_unfolded and (model.fold_embedding or model.fold_first_step):
+        model.kernel_events = None
+        model.fold_embedding = model.fold_first_step = False
+        for i in range(5):
+            step(i)
+        model.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        n_unf = max(10, args.steps // 3)
+        t0 = time.perf_counter()
+        for i in range(n_unf):
+            step(i)
+        model.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        e_unf = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([e_unf], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            e_unf = float(t)
+        if rank == 0:
+            out['value_unfolded'] = world * B * n_unf / e_unf
+            out['ms_per_step_unfolded'] = e_unf / n_unf * 1e3
+            out['unfolded_steps'] = n_unf
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(B, R, Dv, L, Vq, C, threads=min(16, os.cpu_count() or 1))
         print(json.dumps(out), flush=True)

@@ -3,7 +3,7 @@ cd $GRAFT_REPO_ROOT
 for round in 1 2; do
   while IFS='|' read -r label envs flags; do
     [ -z "$label" ] && continue
-    out=$(env $envs timeout -k 10 200 python bench.py --no-cpu-baseline --steps 100 --warmup 20 $flags 2>/dev/null | tail -1) || exit 1
+    out=$(env $envs timeout -k 10 200 python bench.py --no-cpu-baseline --no-unfolded --steps 100 --warmup 20 $flags 2>/dev/null | tail -1) || exit 1
     echo "$label round $round: $(echo "$out" | python -c 'import json,sys; d=json.loads(sys.stdin.read()); print(round(d["value"]), "samples/s", round(d["ms_per_step"]*1000,1), "us/step  attn_fwd", round(d["roofline"]["avg_launch_ms"]*1000,1), "us")')"
   done < $1
 done

@@ -7,6 +7,6 @@ timeout -k 10 400 python bench.py > gpurun_out/bench_final.json
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/ktrace
 cd $R
-timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/ktrace -- python3 $R/bench.py --no-cpu-baseline > $R/gpurun_out/bench_under_rocprof.json
-timeout -k 10 200 python bench.py --no-cpu-baseline --batch 512 --regions 576 --hops 2 --steps 20 --warmup 5 > gpurun_out/bench_cfg5.json
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/ktrace -- python3 $R/bench.py --no-cpu-baseline --no-unfolded > $R/gpurun_out/bench_under_rocprof.json
+timeout -k 10 200 python bench.py --no-cpu-baseline --no-unfolded --batch 512 --regions 576 --hops 2 --steps 20 --warmup 5 > gpurun_out/bench_cfg5.json
 timeout -k 10 300 python tools/encoder_bench.py > gpurun_out/encoder_bench.txt 2>&1

@@ -127,7 +127,7 @@ class _VQAHeadModel(nn.Module):
                  question_out: int = QUESTION_OUT, visual_out: int = VISUAL_OUT,
                  attention_dim: int = FUSION_IN, fusion_in: int = FUSION_IN,
                  fusion_hidden: int = FUSION_HIDDEN, hops: int = 1, dropout: float = DROPOUT_F,
-                 caption_vocab: int = 0, caption_dim: int = 384, seed: int = 0, gemm_engine: int = 0,
+                 caption_vocab=0, caption_dim: int = 384, seed: int = 0, gemm_engine: int = 0,
                  seq2vec_arch: str = 'lstm', seq2vec_dropout: float = 0.3, train_encoder: bool = False):
         super().__init__()
         self.args = args
@@ -140,6 +140,13 @@ class _VQAHeadModel(nn.Module):
         self.E, self.Hq, self.Dv = emb_size, question_out, visual_out
         self.A, self.F, self.Hf = attention_dim, fusion_in, fusion_hidden
         self.hops, self.drop_p = hops, float(dropout)
+        # caption_vocab: the number of caption words, or the word list itself (captions may then be passed to forward
+        # as the reference passes them: the collated strings of model.py:1673)
+        self.caption_tokenizer = None
+        if not isinstance(caption_vocab, int):
+            from .captions import CaptionTokenizer
+            self.caption_tokenizer = caption_vocab if isinstance(caption_vocab, CaptionTokenizer) else CaptionTokenizer(caption_vocab)
+            caption_vocab = len(self.caption_tokenizer)
         self.Ec = caption_dim if caption_vocab > 0 else 0
         self.caption_vocab = caption_vocab
         self.gemm_engine = gemm_engine
@@ -179,6 +186,7 @@ class _VQAHeadModel(nn.Module):
                     m.bias.copy_((torch.rand(m.bias.shape, generator=gen) * 2 - 1) * b)
 
         self.base_seed = seed
+        self.dropout_rank = 0         # data-parallel rank: decorrelates the dropout masks of the ranks (dropout_seed)
         self.step_count = 0           # optimiser steps taken by train_step
         self.drop_step = 0            # dropout stream position
         self._flat = None
@@ -449,7 +457,10 @@ class _VQAHeadModel(nn.Module):
         an arena of their own and are reduced later, together with the other deferred ones, by _flush_wgrads().
         swapped: the product runs as x^T dy (N x M) and the split-K reduction transposes it back."""
         if swapped:
+            ev = self._event_pair('wgrad:' + wname)
             slab, sk, stride = self._gemm_slabs(x, ldx, 0, dy, ld_dy, 0, N, M, K, active_k=active_k)
+            if ev is not None:
+                ev[1].record()
             call('vqa_slab_sum_transpose', ptr(slab), sk, stride, N, M, ptr(self._g(wname)), N)
             return
         sk = call('vqa_gemm_splitk_hint', M, N, K, 0, 0)
@@ -540,7 +551,9 @@ class _VQAHeadModel(nn.Module):
         events on the launch stream around one kernel; the start event is recorded here."""
         if self.kernel_events is None:
             return None
-        n = self._event_calls.get(name, 0)
+        if name not in self._event_calls:      # kernels are sampled on different steps: an event pair costs the stream ~10 us
+            self._event_calls[name] = len(self._event_calls)
+        n = self._event_calls[name]
         self._event_calls[name] = n + 1
         if n % self.kernel_event_stride:
             return None
@@ -561,8 +574,16 @@ class _VQAHeadModel(nn.Module):
             raise ValueError('question_tokens must be (B, L) with the batch of the image input')
         if self.Ec:
             if captions is None:
-                raise ValueError('this model was built with a caption stream: pass captions (B, Tc) int64')
+                raise ValueError('this model was built with a caption stream: pass captions (B, Tc) int64 or the '
+                                 'collated caption strings')
+            if not torch.is_tensor(captions):            # the reference's form: strings (model.py:1673)
+                if self.caption_tokenizer is None:
+                    raise ValueError('caption strings need the model built with the caption word list '
+                                     '(caption_vocab=[...] or a CaptionTokenizer)')
+                captions = self.caption_tokenizer.encode(captions, device=dev)
             captions = captions.long().contiguous()
+            if captions.dim() != 2 or captions.shape[0] != nb:
+                raise ValueError('captions must be (B, Tc) with the batch of the image input')
         else:
             captions = None
         return feats, tokens, captions
@@ -586,7 +607,13 @@ class _VQAHeadModel(nn.Module):
         if not self.training:
             return (0,) * 6, 0.0
         self.drop_step += 1
-        return tuple(site_seed(self.base_seed, self.drop_step, s) for s in range(6)), self.drop_p
+        return tuple(site_seed(self.dropout_seed(), self.drop_step, s) for s in range(6)), self.drop_p
+
+    def dropout_seed(self) -> int:
+        """Base seed of the dropout stream.  The masks hash (seed, local row, column), so data-parallel ranks that
+        share a seed would drop the same elements of their local samples: each rank offsets the seed by its
+        ``dropout_rank`` (set it to the process rank; weights still initialise from the shared ``base_seed``)."""
+        return (self.base_seed + 1000003 * int(self.dropout_rank)) & 0x7FFFFFFF
 
     def encode_question(self, tokens: torch.Tensor, ws=None, seeds=None, q_drop=None) -> torch.Tensor:
         """Embedding gather + LSTM layer(s) + last-valid-step selection -> q (B, Hq) fp32
@@ -659,7 +686,10 @@ class _VQAHeadModel(nn.Module):
                      seeds[li], self.seq2vec_dropout, dt)
         return ws['q32']
 
-    overlap_encoder = True        # frozen question encoder on a second stream beside the image side (see _forward_impl)
+    # frozen question encoder on a second stream beside the image side (see _forward_impl).  Off by default: the
+    # region projection holds every CU's LDS, so the encoder's kernels only run as its workgroups retire (-6 us per
+    # step same-box, and the projection's own span grows by what the encoder takes)
+    overlap_encoder = False
 
     def _side_stream(self, device):
         st = getattr(self, '_side', None)
@@ -1107,12 +1137,15 @@ class VQAAttnModel(_VQAHeadModel):
         A, Dv, dt = self.A, self.Dv, self.dt
         ldA = self._ldA()
         pre = f'attention.{k}.'
+        ev = self._event_pair(f'proj:{k}')
         if k == 0 and self.fuse_row_norm:       # inv_norm written by the same launch
             call('vqa_gemm_fused_rownorm', ptr(feats), Dv, ptr(self._w(pre + 'linear_va.weight')), Dv, ptr(ws[f'P{k}']), ldA,
                  B * R, A, Dv, ptr(self._f32(pre + 'linear_va.bias')), ptr(ws['inv_norm']), 0, dt, dt, self.gemm_engine)
         else:
             call('vqa_gemm_fused', ptr(feats), Dv, 1, ptr(self._w(pre + 'linear_va.weight')), Dv, 1, ptr(ws[f'P{k}']), ldA,
                  B * R, A, Dv, ptr(self._f32(pre + 'linear_va.bias')), ptr(ws['inv_norm']), 0, dt, dt, self.gemm_engine)
+        if ev is not None:
+            ev[1].record()
 
     def _visual_early(self, ws, feats, B):
         # every hop's region projection reads the features and its own weights only: none waits for the question

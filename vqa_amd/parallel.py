@@ -49,6 +49,10 @@ class GradReducer:
         self._next = 0                      # first bucket not yet handed to a collective or to the pending run
         self._run: Optional[Tuple[int, int]] = None   # element range of the completed buckets being held back
         self.launched: List[Tuple[int, int]] = []     # element ranges of the collectives of this pass, in order
+        # timing (switched on by setting `timing = {}`): per collective the bytes and an event on the compute stream
+        # at its launch; per wait an event pair on the compute stream around the cross-stream wait.  The wait pair is
+        # the communication the compute stream could not hide; launch -> end of the wait bounds the collective's span.
+        self.timing: Optional[dict] = None
 
     def begin(self, model) -> None:
         """Bind to the model's flat gradient buffer for one backward pass."""
@@ -62,6 +66,10 @@ class GradReducer:
 
     def _launch(self, s: int, e: int):
         self.launched.append((s, e))
+        if self.timing is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self.timing.setdefault('launch', []).append((4 * (e - s), ev))
         return dist.all_reduce(self._flat_grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def bucket_ready(self, index: int) -> None:
@@ -113,11 +121,20 @@ class GradReducer:
         # RCCL runs a group's collectives in order on one stream: making the compute stream wait for the
         # youngest one covers the older ones, and each wait that is saved is one cross-stream dependency
         # less on the GPU.  Other backends complete their work items independently.
-        if handles and self._in_order:
+        if not handles:
+            return
+        pair = None
+        if self.timing is not None:
+            pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            pair[0].record()
+        if self._in_order:
             handles[-1].wait()
         else:
             for h in handles:
                 h.wait()
+        if pair is not None:
+            pair[1].record()
+            self.timing.setdefault('wait', []).append(pair)
 
     def finish_last(self) -> None:
         """Wait for whatever finish(defer_last=True) or defer_everything() left in flight."""

@@ -104,6 +104,23 @@ def train(model, train_dataset, validate_dataset, num_epochs, learning_rate, arg
     return history
 
 
+def model_and_geometry(args, dev, **model_kw):
+    """The model class chosen by ``args.model`` (the if / elif chain of train.py:311-338, test.py:176-203) on
+    ``dev`` and the shapes of the synthetic data that feeds it."""
+    classes = {'VQAAttnModel': VQAAttnModel, 'VQAGAPModel': VQAGAPModel, 'VQAModel': VQAModel}
+    if args.model not in classes:
+        raise SystemExit('--model must be one of ' + ', '.join(classes))
+    Vq, C, L, R, Dv = 10000, 3000, 14, 196, 2048
+    input_size, stage_maps = 512, None
+    if args.model == 'VQAGAPModel':       # ResNet-152 stage outputs of a 256 x 256 image (the LR tiles)
+        input_size, stage_maps = 256, ((256, 64), (512, 32), (1024, 16), (2048, 8))
+    elif args.model == 'VQAModel':        # last ResNet map of a 512 x 512 image: 16 x 16 x 2048
+        R = (input_size // 32) ** 2
+    model = classes[args.model](['<EOS>'] + [f'w{i}' for i in range(Vq - 1)], ['<EOS>'] + [f'a{i}' for i in range(C - 1)],
+                                args, input_size, **model_kw).to(dev)
+    return model, {'Vq': Vq, 'C': C, 'L': L, 'R': R, 'Dv': Dv, 'stage_maps': stage_maps}
+
+
 def main(argv=None):
     parser = argparse.ArgumentParser(description='MI355X VQA training')
     parser.add_argument('--bs', type=int, default=40)
@@ -115,23 +132,15 @@ def main(argv=None):
     parser.add_argument('--out', type=str, default=None, help='checkpoint directory (reference: ../data/dump-models/<dataset>)')
     parser.add_argument('--resume', type=str, default=None, help='TrainState_<model>.pth to continue from')
     args = parser.parse_args(argv)
-    classes = {'VQAAttnModel': VQAAttnModel, 'VQAGAPModel': VQAGAPModel, 'VQAModel': VQAModel}
-    if args.model not in classes:
-        raise SystemExit('--model must be one of ' + ', '.join(classes))
     if args.dataset != 'SYNTH':
         raise SystemExit('only --dataset SYNTH is available (LR / HR need image files and a feature extractor)')
     dev = torch.device(f'cuda:{args.gpu}')
     torch.cuda.set_device(dev)
-    Vq, C, L, R, Dv = 10000, 3000, 14, 196, 2048
-    input_size, stage_maps = 512, None
-    if args.model == 'VQAGAPModel':       # ResNet-152 stage outputs of a 256 x 256 image (the LR tiles)
-        input_size, stage_maps = 256, ((256, 64), (512, 32), (1024, 16), (2048, 8))
-    elif args.model == 'VQAModel':        # last ResNet map of a 512 x 512 image: 16 x 16 x 2048
-        R = (input_size // 32) ** 2
-    train_ds = SynthVQADataset(8, args.bs, R, Dv, L, Vq, C, dev, seed=42, stage_maps=stage_maps)
-    val_ds = SynthVQADataset(2, args.bs, R, Dv, L, Vq, C, dev, seed=43, stage_maps=stage_maps)
-    model = classes[args.model](['<EOS>'] + [f'w{i}' for i in range(Vq - 1)], ['<EOS>'] + [f'a{i}' for i in range(C - 1)],
-                                args, input_size).to(dev)
+    model, geo = model_and_geometry(args, dev)
+    train_ds = SynthVQADataset(8, args.bs, geo['R'], geo['Dv'], geo['L'], geo['Vq'], geo['C'], dev, seed=42,
+                               stage_maps=geo['stage_maps'])
+    val_ds = SynthVQADataset(2, args.bs, geo['R'], geo['Dv'], geo['L'], geo['Vq'], geo['C'], dev, seed=43,
+                             stage_maps=geo['stage_maps'])
     return train(model, train_ds, val_ds, args.epochs, args.lr, args, args.dataset, args.out, args.resume)
 
 
