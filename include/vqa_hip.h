@@ -40,6 +40,13 @@ extern "C" {
 #define VQA_F32 0
 #define VQA_BF16 1
 
+/* Device-side status words (int32_t status[VQA_STATUS_WORDS], zeroed by the caller): kernels that meet an input the
+ * reference would raise for set a word to 1 and carry on (nothing here synchronises); the host reads the words when
+ * it next synchronises anyway. */
+#define VQA_STATUS_BAD_TOKEN 0     /* a question token id outside the embedding table (nn.Embedding raises IndexError) */
+#define VQA_STATUS_BAD_TARGET 1    /* an answer id outside [0, C) (CrossEntropyLoss raises "Target out of bounds") */
+#define VQA_STATUS_WORDS 2
+
 int vqa_version(void);
 const char* vqa_last_error_string(void);
 
@@ -68,7 +75,9 @@ int vqa_lstm_cell(const float* slabs, int nslab, size_t slab_stride, const void*
  *   order); active[t] = #rows with steps > t; offsets[t] = sum of active[0:t], offsets[L] = their total.
  *   One workgroup; B + 18 (L + 1) <= 16384.                        seq2vec.py:11-14, 16-25 */
 int vqa_sequence_pack(const int64_t* tokens, int B, int L, int32_t* lengths, int32_t* perm, int32_t* active,
-                      int32_t* offsets, hipStream_t stream);
+                      int32_t* offsets, long n_table_rows, int32_t* status, hipStream_t stream);
+/* (status, optional, with n_table_rows > 0: status[VQA_STATUS_BAD_TOKEN] = 1 if any token id lies outside
+ *  [0, n_table_rows); the gather kernels read the pad row for such an id) */
 /* out[offsets[t] + j, 0:width] = act(table[tokens[perm[j], t], 0:width]) for j < active[t]; act 0 none,
  * 1 tanh (TwoLSTM applies tanh to the embeddings)                  seq2vec.py:42, 63-64 */
 int vqa_embedding_gather_packed(const int64_t* tokens, const void* table, void* out, int B, int L, int width,
@@ -334,7 +343,9 @@ int vqa_cast_pad(const float* src, int ld_src, void* dst, int ld_dst, int M, int
  * (columns C..ld_d-1 of dlogits are zeroed); dlogits may be NULL.
  *                             train.py:35, 201 (CrossEntropyLoss) and 203 (backward) */
 int vqa_softmax_ce(const float* logits, int ld, const int64_t* target, float* loss_rows, void* dlogits, int ld_d,
-                   int B, int C, float grad_scale, int dtype, hipStream_t stream);
+                   int B, int C, float grad_scale, int dtype, int32_t* status, hipStream_t stream);
+/* (a target outside [0, C): that row's loss and gradient are NaN and, with status given,
+ *  status[VQA_STATUS_BAD_TARGET] = 1; there is no ignore_index) */
 /* out[0] = scale * sum(x[0:n]) in a fixed order (mean reduction of the loss) */
 int vqa_sum_scale(const float* x, float* out, int n, float scale, hipStream_t stream);
 

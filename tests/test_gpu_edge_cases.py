@@ -86,3 +86,38 @@ def test_rejected_inputs_raise():
         m(torch.zeros((2, 5, kw['Dv'] + 8), device='cuda'), torch.zeros((2, 7), dtype=torch.long, device='cuda'))
     with pytest.raises(ValueError):                             # batch mismatch
         m(torch.zeros((2, 5, kw['Dv']), device='cuda'), torch.zeros((3, 7), dtype=torch.long, device='cuda'))
+
+
+def test_out_of_range_ids_raise_at_the_next_sync():
+    """nn.Embedding raises for a token id outside its table (seq2vec.py:42) and CrossEntropyLoss for a target outside
+    [0, C) (train.py:201).  The kernels cannot raise: they set a device-side status word (a bad target also makes its
+    row's loss NaN) and the module raises IndexError at the next sync() / state_dict()."""
+    from vqa_amd.model import VQAAttnModel
+    kw = dict(vq=30, C=11, E=12, Hq=24, Dv=32, A=16, F=16, Hf=8)
+    m = VQAAttnModel(['w'] * kw['vq'], ['a'] * kw['C'], None, dtype=torch.float32, emb_size=kw['E'], question_out=kw['Hq'],
+                     visual_out=kw['Dv'], attention_dim=kw['A'], fusion_in=kw['F'], fusion_hidden=kw['Hf'], seed=77).to('cuda')
+    b = vqa_ref.synthetic_batch(4, 9, kw['Dv'], 7, kw['vq'], kw['C'], seed=1)
+    f, t, a = b['feats'].cuda(), b['tokens'].cuda(), b['answers'].cuda()
+    m.train_step(f, t, a)
+    m.sync()                                           # clean inputs: nothing raised
+    bad_t = t.clone()
+    bad_t[1, 0] = kw['vq'] + 1                         # the table has vq + 1 rows: ids 0 .. vq
+    m.eval()
+    with torch.no_grad():
+        m(f, bad_t)
+    with pytest.raises(IndexError, match='question token'):
+        m.sync()
+    m.sync()                                           # the words were cleared by the check
+    bad_a = a.clone()
+    bad_a[2] = kw['C']
+    m.train()
+    loss = m.train_step(f, t, bad_a)
+    assert torch.isnan(loss).item()
+    with pytest.raises(IndexError, match='Target out of bounds'):
+        m.state_dict()
+    bad_a[2] = -1
+    m2 = VQAAttnModel(['w'] * kw['vq'], ['a'] * kw['C'], None, dtype=torch.bfloat16, emb_size=kw['E'], question_out=kw['Hq'],
+                      visual_out=kw['Dv'], attention_dim=kw['A'], fusion_in=kw['F'], fusion_hidden=kw['Hf'], seed=77).to('cuda')
+    m2.train_step(f, t, bad_a)
+    with pytest.raises(IndexError, match='Target out of bounds'):
+        m2.sync()

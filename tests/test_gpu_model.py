@@ -367,7 +367,7 @@ def test_sequence_pack_bit_exact(B, L):
     out = {k: torch.full((n,), -7, dtype=torch.int32, device='cuda') for k, n in
            (('len', B), ('perm', B), ('m_t', L), ('offs', L + 1))}
     _lib.bind_stream()
-    call('vqa_sequence_pack', ptr(t), B, L, ptr(out['len']), ptr(out['perm']), ptr(out['m_t']), ptr(out['offs']))
+    call('vqa_sequence_pack', ptr(t), B, L, ptr(out['len']), ptr(out['perm']), ptr(out['m_t']), ptr(out['offs']), 0, None)
     ln = L - (tok == 0).sum(1)
     assert np.array_equal(out['len'].cpu().numpy(), vqa_ref.process_lengths(torch.from_numpy(tok)).numpy())
     steps = np.where(ln == 0, L, ln)
@@ -415,7 +415,7 @@ def test_softmax_ce_fixture(golden_dir):
     rows = torch.zeros(B, device='cuda')
     dl = torch.zeros(B, 16, device='cuda')
     out = torch.zeros(1, device='cuda')
-    call('vqa_softmax_ce', ptr(lg), C, ptr(y), ptr(rows), ptr(dl), 16, B, C, 1.0 / B, F32)
+    call('vqa_softmax_ce', ptr(lg), C, ptr(y), ptr(rows), ptr(dl), 16, B, C, 1.0 / B, F32, None)
     call('vqa_sum_scale', ptr(rows), ptr(out), B, 1.0 / B)
     torch.cuda.synchronize()
     assert abs(float(out) - float(z['loss'])) <= 1e-6 * abs(float(z['loss']))

@@ -24,7 +24,7 @@ _SIGNATURES = {
     'vqa_process_lengths': [_p, _p, _i, _i, _p],
     'vqa_embedding_gather': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     'vqa_lstm_cell': [_p, _i, _z, _p, _i, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
-    'vqa_sequence_pack': [_p, _i, _i, _p, _p, _p, _p, _p],
+    'vqa_sequence_pack': [_p, _i, _i, _p, _p, _p, _p, _l, _p, _p],
     'vqa_embedding_gather_packed': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _i, _p, _i, _p],
     'vqa_lstm_cell_packed': [_p, _i, _z, _p, _i, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p, _p, _p, _u, _f, _i, _p],
     'vqa_lstm_cell_packed_table': [_p, _i, _z, _p, _i, _i, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p, _u, _f, _p, _i, _p],
@@ -68,7 +68,7 @@ _SIGNATURES = {
     'vqa_tanh_dropout_bwd': [_p, _i, _z, _p, _i, _p, _i, _i, _i, _u, _f, _i, _p],
     'vqa_colsum': [_p, _i, _p, _i, _i, _i, _p],
     'vqa_cast_pad': [_p, _i, _p, _i, _i, _i, _i, _p],
-    'vqa_softmax_ce': [_p, _i, _p, _p, _p, _i, _i, _i, _f, _i, _p],
+    'vqa_softmax_ce': [_p, _i, _p, _p, _p, _i, _i, _i, _f, _i, _p, _p],
     'vqa_sum_scale': [_p, _p, _i, _f, _p],
     'vqa_argmax_accuracy': [_p, _i, _i, _i, _p, _p, _i, _p, _p, _p],
     'vqa_adam_step': [_p, _p, _p, _p, _p, _l, _f, _f, _f, _f, _i, _f, _p],

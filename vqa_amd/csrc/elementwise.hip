@@ -34,7 +34,8 @@ __global__ void k_process_lengths(const int64_t* __restrict__ tok, int* __restri
 //              offs[L] = total number of (row, step) pairs
 __global__ void __launch_bounds__(1024) k_sequence_pack(const int64_t* __restrict__ tok, int B, int L,
                                                         int* __restrict__ len, int* __restrict__ perm,
-                                                        int* __restrict__ m_t, int* __restrict__ offs) {
+                                                        int* __restrict__ m_t, int* __restrict__ offs,
+                                                        long n_rows, int* __restrict__ status) {
     extern __shared__ int sm[];
     int* steps = sm;                 // [B]   zero count, then step count
     int* above = steps + B;          // [L+1] above[n] = rows with more than n steps (n = 0..L)
@@ -44,8 +45,13 @@ __global__ void __launch_bounds__(1024) k_sequence_pack(const int64_t* __restric
     for (int b = tid; b < B; b += blockDim.x) steps[b] = 0;
     for (int n = tid; n <= L; n += blockDim.x) { above[n] = 0; run[n] = 0; }
     __syncthreads();
-    for (long i = tid; i < (long)B * L; i += blockDim.x)              // coalesced pass over the tokens
-        if (tok[i] == 0) atomicAdd(&steps[i / L], 1);
+    bool bad = false;
+    for (long i = tid; i < (long)B * L; i += blockDim.x) {            // coalesced pass over the tokens
+        const int64_t v = tok[i];
+        if (v == 0) atomicAdd(&steps[i / L], 1);
+        bad |= v < 0 || v >= n_rows;
+    }
+    if (status && n_rows > 0 && bad) status[VQA_STATUS_BAD_TOKEN] = 1;   // (same value from every lane that sees one)
     __syncthreads();
     for (int b = tid; b < B; b += blockDim.x) {
         const int z = steps[b];
@@ -700,7 +706,7 @@ template <typename T>
 __global__ void __launch_bounds__(256) k_softmax_ce(const float* __restrict__ logits, int ld,
                                                     const int64_t* __restrict__ target,
                                                     float* __restrict__ loss_row, T* __restrict__ dlogits,
-                                                    int ld_d, int C, float scale) {
+                                                    int ld_d, int C, float scale, int* __restrict__ status) {
     __shared__ float red[8];
     const int b = blockIdx.x;
     const float* z = logits + (size_t)b * ld;
@@ -729,9 +735,15 @@ __global__ void __launch_bounds__(256) k_softmax_ce(const float* __restrict__ lo
     }
     se = block_sum(se, red);
     const int64_t y = target[b];
-    if (threadIdx.x == 0) loss_row[b] = (y >= 0 && y < C) ? (logf(se) - (z[y] - mx)) : 0.f;
+    // a target outside [0, C) (torch.nn.CrossEntropyLoss raises for it): the row's loss and gradient are NaN, so the
+    // mistake cannot train silently, and the status word tells the host what happened
+    const bool bad = y < 0 || y >= C;
+    if (threadIdx.x == 0) {
+        loss_row[b] = bad ? __builtin_nanf("") : (logf(se) - (z[y] - mx));
+        if (bad && status) status[VQA_STATUS_BAD_TARGET] = 1;
+    }
     if (dlogits) {
-        const float inv = 1.0f / se;
+        const float inv = bad ? __builtin_nanf("") : 1.0f / se;
         if (keep) {
 #pragma unroll
             for (int k = 0; k < KEEP; ++k) {
@@ -1006,12 +1018,12 @@ int vqa_embedding_gather(const int64_t* tokens, const void* table, void* out, in
 }
 
 int vqa_sequence_pack(const int64_t* tokens, int B, int L, int32_t* lengths, int32_t* perm, int32_t* active,
-                      int32_t* offsets, hipStream_t stream) {
+                      int32_t* offsets, long n_table_rows, int32_t* status, hipStream_t stream) {
     VQA_REQUIRE(tokens && lengths && perm && active && offsets && B >= 0 && L > 0, "vqa_sequence_pack: bad arguments");
     const size_t lds = (size_t)(B + 18 * (L + 1)) * sizeof(int);
     VQA_REQUIRE(lds <= 64 * 1024, "vqa_sequence_pack: B + 18 (L + 1) must be <= 16384");
     if (B == 0) return 0;
-    k_sequence_pack<<<1, 1024, lds, stream>>>(tokens, B, L, lengths, perm, active, offsets);
+    k_sequence_pack<<<1, 1024, lds, stream>>>(tokens, B, L, lengths, perm, active, offsets, n_table_rows, status);
     return vqa_check_launch("vqa_sequence_pack");
 }
 
@@ -1323,11 +1335,11 @@ int vqa_cast_pad(const float* src, int ld_src, void* dst, int ld_dst, int M, int
 }
 
 int vqa_softmax_ce(const float* logits, int ld, const int64_t* target, float* loss_rows, void* dlogits, int ld_d,
-                   int B, int C, float grad_scale, int dtype, hipStream_t stream) {
+                   int B, int C, float grad_scale, int dtype, int32_t* status, hipStream_t stream) {
     VQA_REQUIRE(logits && target && loss_rows && B >= 0 && C > 0 && ld >= C, "vqa_softmax_ce: bad arguments");
     VQA_REQUIRE(!dlogits || ld_d >= C, "vqa_softmax_ce: ld_d < C");
     if (B == 0) return 0;
-    DISPATCH_T(dtype, (k_softmax_ce<T><<<B, 256, 0, stream>>>(logits, ld, target, loss_rows, (T*)dlogits, ld_d, C, grad_scale)));
+    DISPATCH_T(dtype, (k_softmax_ce<T><<<B, 256, 0, stream>>>(logits, ld, target, loss_rows, (T*)dlogits, ld_d, C, grad_scale, status)));
     return vqa_check_launch("vqa_softmax_ce");
 }
 

@@ -630,7 +630,8 @@ class _VQAHeadModel(nn.Module):
         fuse_drop = q_drop is not None and not two     # (buffer, seed, p): the head's dropout of q written by the cell kernel
         # packed sequences: rows sorted by length, so the rows still running at step t are the first
         # m_t[t] and their input projections are rows offs[t].. of xg; padding steps cost nothing
-        call('vqa_sequence_pack', ptr(tokens), B, L, ptr(ws['len']), ptr(ws['perm']), ptr(ws['m_t']), ptr(ws['offs']))
+        call('vqa_sequence_pack', ptr(tokens), B, L, ptr(ws['len']), ptr(ws['perm']), ptr(ws['m_t']), ptr(ws['offs']),
+             self._emb_t.shape[0], ptr(self._status_words(dev)))
         table = self._xg_table                  # frozen encoder: gather + first input projection come from one table
         if table is None:
             call('vqa_embedding_gather_packed', ptr(tokens), ptr(self._emb_t), ptr(ws['x_emb']), B, L, Ep, Ep, Ep,
@@ -916,7 +917,7 @@ class _VQAHeadModel(nn.Module):
         ans = answers.long().contiguous()
         _lib.bind_stream()
         call('vqa_softmax_ce', ptr(ws['logits']), Cp, ptr(ans), ptr(ws['loss_rows']), ptr(ws['dlogits']), Cp, B, C,
-             1.0 / B, self.dt)
+             1.0 / B, self.dt, ptr(self._status_words(ans.device)))
         if reduce:                      # (train_step folds this mean into the backward pass's batched column sums)
             call('vqa_sum_scale', ptr(ws['loss_rows']), ptr(ws['loss']), B, 1.0 / B)
         self._loss_pending = not reduce
@@ -963,8 +964,35 @@ class _VQAHeadModel(nn.Module):
         self._adam_range(lo, hi, lr, betas, eps, step, scale)
 
     def sync(self):
-        """Make every parameter current (applies a deferred last-bucket update, if any)."""
+        """Make every parameter current (applies a deferred last-bucket update, if any) and raise for inputs the
+        kernels flagged since the last check."""
         self._finish_pending()
+        self.check_status()
+
+    def _status_words(self, device) -> torch.Tensor:
+        st = getattr(self, '_status', None)
+        if st is None or st.device != device:
+            self._status = st = torch.zeros(2, dtype=torch.int32, device=device)
+        return st
+
+    def check_status(self) -> None:
+        """Read the device-side status words (one small copy, which synchronises with the stream) and raise what the
+        reference's stock modules would have raised at the offending call: IndexError for a question token outside
+        the embedding table (nn.Embedding, seq2vec.py:42) or an answer id outside [0, C) (CrossEntropyLoss,
+        train.py:201).  The kernels do not stop: a bad token reads the pad row, a bad target makes its row's loss and
+        gradient NaN.  Called by sync(), state_dict() and the train / evaluation drivers."""
+        st = getattr(self, '_status', None)
+        if st is None:
+            return
+        tok, tgt = st.tolist()
+        if tok or tgt:
+            st.zero_()
+            what = []
+            if tok:
+                what.append(f'a question token id outside [0, {self.seq2vec.embedding.num_embeddings})')
+            if tgt:
+                what.append(f'an answer id outside [0, {self.num_classes}) (Target out of bounds)')
+            raise IndexError(f'{type(self).__name__}: ' + ' and '.join(what) + ' reached the kernels since the last check')
 
     def train_step(self, input_v, input_q, answers, captions=None, lr: float = 1e-5, reducer=None) -> torch.Tensor:
         """forward + loss + backward (+ gradient all-reduce through `reducer`) + Adam
@@ -1032,6 +1060,7 @@ class _VQAHeadModel(nn.Module):
     # ------------------------------------------------------------------ torch plumbing
     def state_dict(self, *a, **kw):
         self._finish_pending()
+        self.check_status()
         return super().state_dict(*a, **kw)
 
     def _apply(self, fn, *a, **kw):

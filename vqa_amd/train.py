@@ -65,6 +65,7 @@ def evaluate(model, dataset, meter):
             meter.update(model, answer, types)
     res = meter.result()
     res['loss'] = float(running) / len(dataset)
+    model.check_status()
     return res
 
 
@@ -91,6 +92,7 @@ def train(model, train_dataset, validate_dataset, num_epochs, learning_rate, arg
             loss = model.train_step(image, question, answer, lr=learning_rate, reducer=reducer)
             running += loss * question.shape[0]
         train_loss = float(running) / len(train_dataset)
+        model.check_status()
         print('epoch #%d loss: %.3f' % (epoch, train_loss))
         history.append({'val': val, 'train_loss': train_loss})
         if out_dir:
