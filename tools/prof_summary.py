@@ -1,7 +1,7 @@
 """Condense a rocprofv3 --kernel-trace --stats output directory into a small text table."""
 import csv, glob, sys, os
 d = sys.argv[1]; steps = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-f = glob.glob(os.path.join(d, '**', '*kernel_stats.csv'), recursive=True)[0]
+f = max(glob.glob(os.path.join(d, '**', '*kernel_stats.csv'), recursive=True), key=os.path.getmtime)   # newest run
 rows = list(csv.DictReader(open(f)))
 tot = sum(float(r['TotalDurationNs']) for r in rows)
 print(f'# source: {f}\n# total kernel time {tot/1e6:.3f} ms over the run; per-step figures divide by {steps} steps')
