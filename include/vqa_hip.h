@@ -122,6 +122,18 @@ int vqa_lstm_cell01_table(const void* xg_table, int ld_xg, const float* hh_table
                           void* hs, int ld_hs, void* q_drop, unsigned drop_seed, float drop_p, int dtype,
                           hipStream_t stream);
 
+/* One whole step t >= 1 on packed sequences in one launch (bf16 storage): the recurrent product h_{t-1} W_hh^T on the
+ * matrix cores with vqa_lstm_cell_packed[_table] as its epilogue (a workgroup owns 128 rows x 16 hidden units and all
+ * four gates of them, over the whole contraction: no partial sums, no second launch).  xg: the packed input
+ * projections (tokens == NULL, row offsets[t] + j) or the per-token table (tokens given, n_table_rows rows).
+ * h_prev (B, ld_h) holds the previous step's outputs in sorted row order; h_out must be a different buffer.
+ * H % 16 == 0.  No state is saved for backward through time.          seq2vec.py:38, 43 (nn.LSTM), 16-25 */
+int vqa_lstm_step(const void* h_prev, int ld_h, const void* w_hh, int ld_w, const void* xg, int ld_xg,
+                  int n_table_rows, const int64_t* tokens, float* c, void* h_out, int ld_ho,
+                  const int32_t* lengths, float* q_f32, void* q_t, int ld_q, int B, int H, int t, int L,
+                  const int32_t* perm, const int32_t* active, const int32_t* offsets, void* hs, int ld_hs,
+                  void* q_drop, unsigned drop_seed, float drop_p, int dtype, hipStream_t stream);
+
 /* Backward through LSTM step t on packed sequences (a trainable question encoder; the reference
  * freezes it, model.py:42-43, so this has no counterpart there beyond autograd of seq2vec.py:43):
  * slabs = dG_{t+1} W_hh partial sums (rows running at t+1), dq (B, ld_dq) in original row order is the

@@ -659,21 +659,33 @@ class _VQAHeadModel(nn.Module):
                      ptr(q_drop[0]) if fuse_drop else None, q_drop[1] if fuse_drop else 0,
                      q_drop[2] if fuse_drop else 0.0, dt)
                 t_first = 2
+            # steps with a recurrent product: one launch each (product + cell, vqa_lstm_step) when nothing has to be
+            # saved for backward through time; h ping-pongs between two buffers (the step reads all of h_{t-1})
+            fused = self.fused_lstm_step and dt == _lib.BF16 and Hh % 16 == 0 and not save
+            h_cur, h_alt = ws['h'], ws['h2']
             for t in range(t_first, L):
                 hh_tab = self._hh_table if (from_table and t == 1) else None     # step 1's recurrent product, tabulated
+                if fused and t > 0 and hh_tab is None:
+                    call('vqa_lstm_step', ptr(h_cur), Hh, ptr(whh), Hh, ptr(table if from_table else ws['xg']), 4 * Hh,
+                         table.shape[0] if from_table else 0, ptr(tokens) if from_table else None, ptr(ws['c']),
+                         ptr(h_alt), Hh, ptr(ws['len']), q32, qT, Hq, B, Hh, t, L, ptr(ws['perm']), ptr(ws['m_t']),
+                         ptr(ws['offs']), ptr(hs), Hh, ptr(q_drop[0]) if fuse_drop else None,
+                         q_drop[1] if fuse_drop else 0, q_drop[2] if fuse_drop else 0.0, dt)
+                    h_cur, h_alt = h_alt, h_cur
+                    continue
                 if t == 0 or hh_tab is not None:
                     slab, sk, stride = None, 0, 0
                 else:
-                    slab, sk, stride = self._gemm_slabs(ws['h'], Hh, 1, whh, Hh, 1, B, 4 * Hh, Hh,
+                    slab, sk, stride = self._gemm_slabs(h_cur, Hh, 1, whh, Hh, 1, B, 4 * Hh, Hh,
                                                         active_rows=ws['m_t'].data_ptr() + 4 * t)
                 if from_table:
                     call('vqa_lstm_cell_packed_table', ptr(slab), sk, stride, ptr(table), 4 * Hh, table.shape[0], ptr(tokens),
-                         ptr(ws['c']), ptr(ws['h']), Hh, ptr(ws['len']), q32, qT, Hq, B, Hh, t, L, ptr(ws['perm']),
+                         ptr(ws['c']), ptr(h_cur), Hh, ptr(ws['len']), q32, qT, Hq, B, Hh, t, L, ptr(ws['perm']),
                          ptr(ws['m_t']), ptr(ws['offs']), ptr(hs), Hh,
                          ptr(q_drop[0]) if fuse_drop else None, q_drop[1] if fuse_drop else 0,
                          q_drop[2] if fuse_drop else 0.0, ptr(hh_tab), dt)
                     continue
-                call('vqa_lstm_cell_packed', ptr(slab), sk, stride, ptr(ws['xg']), 4 * Hh, ptr(ws['c']), ptr(ws['h']), Hh,
+                call('vqa_lstm_cell_packed', ptr(slab), sk, stride, ptr(ws['xg']), 4 * Hh, ptr(ws['c']), ptr(h_cur), Hh,
                      ptr(ws['len']), q32, qT, Hq, B, Hh, t, L, ptr(ws['perm']), ptr(ws['m_t']),
                      ptr(ws['offs']), ptr(hs), Hh, ptr(gates), ptr(cs),
                      ptr(q_drop[0]) if fuse_drop else None, q_drop[1] if fuse_drop else 0, q_drop[2] if fuse_drop else 0.0, dt)
@@ -691,6 +703,10 @@ class _VQAHeadModel(nn.Module):
     # region projection holds every CU's LDS, so the encoder's kernels only run as its workgroups retire (-6 us per
     # step same-box, and the projection's own span grows by what the encoder takes)
     overlap_encoder = False
+    # recurrent product + cell update of a step in one launch (vqa_lstm_step; bf16, nothing saved for BPTT).  Off by
+    # default: every workgroup has to read all of h_{t-1}, twice the operand traffic of the split-K product, and the
+    # step got slower (+76 us per train step same-box at B = 256, Hq = 2400)
+    fused_lstm_step = False
 
     def _side_stream(self, device):
         st = getattr(self, '_side', None)
@@ -719,7 +735,7 @@ class _VQAHeadModel(nn.Module):
         Hh = max(rnn.hidden_size for rnn in self.seq2vec.layers)
         ws.update({'len': z((B,), torch.int32), 'perm': z((B,), torch.int32), 'm_t': z((L,), torch.int32),
                    'offs': z((L + 1,), torch.int32), 'x_emb': z((L * B, Ep), tdt), 'xg': z((L * B, 4 * Hh), tdt),
-                   'c': z((B, Hh), f32), 'h': z((B, Hh), tdt), 'q32': z((B, H), f32), 'qT': z((B, H), tdt)})
+                   'c': z((B, Hh), f32), 'h': z((B, Hh), tdt), 'h2': z((B, Hh), tdt), 'q32': z((B, H), f32), 'qT': z((B, H), tdt)})
         if len(self.seq2vec.layers) > 1:
             ws['hs'] = z((L * B, Hh), tdt)
         if self.train_encoder:                        # state kept for backward through time
