@@ -26,6 +26,19 @@ def run_fused(name, M, N, K, engines, ldc=None):
         us = timeit(lambda: call('vqa_gemm_fused', ptr(A), K, 1, ptr(Bm), K, 1, ptr(C), ldc, M, N, K, ptr(bias), ptr(rs), 0, 1, 1, eng))
         print(f'{name:12s} fused bf16 out ldc={ldc} M={M:6d} N={N:5d} K={K:6d} engine={eng:2d}: {us:8.1f} us  {2.0 * M * N * K / us / 1e6:7.1f} TF')
 
+def run_rownorm(name, M, N, K, ldc):
+    """projection with the row norms fused (the step's call) against row-scale from a separate pass"""
+    dt = torch.bfloat16
+    A = (torch.randn((M, K), device='cuda')).clamp_min_(0).to(dt)
+    Bm = (torch.randn((N, K), device='cuda') * 0.02).to(dt)
+    bias = torch.randn(N, device='cuda'); inv = torch.empty(M, device='cuda')
+    C = torch.empty((M, ldc), device='cuda', dtype=dt)
+    for label, fn in (('fused row norms', lambda: call('vqa_gemm_fused_rownorm', ptr(A), K, ptr(Bm), K, ptr(C), ldc, M, N, K, ptr(bias), ptr(inv), 0, 1, 1, 0)),
+                      ('row scale given', lambda: call('vqa_gemm_fused', ptr(A), K, 1, ptr(Bm), K, 1, ptr(C), ldc, M, N, K, ptr(bias), ptr(inv), 0, 1, 1, 0)),
+                      ('inv_norm pass  ', lambda: call('vqa_inv_norm', ptr(A), ptr(inv), M, K, K, 1))):
+        us = timeit(fn)
+        print(f'{name:10s} {label} ldc={ldc}: {us:8.1f} us')
+
 def run(name, M, N, K, akm, bkm, variants, ldb=None):
     dt = torch.bfloat16
     A = (torch.randn((M, K) if akm else (K, M), device='cuda') * 0.5).to(dt)
@@ -66,6 +79,9 @@ if __name__ == '__main__':
         for _ in range(3):
             run('wgrad TN swapped', 2048, 1200, 50176, False, False, [(6, 6), (10, 6), (10, 5), (10, 7)])
             run('wgrad TN sw ld1280', 2048, 1200, 50176, False, False, [(6, 6), (10, 6)], ldb=1280)
+    elif which == 'norm':
+        for _ in range(3):
+            run_rownorm('K4 fwd', 50176, 1200, 2048, 1280)
     elif which == 'probe':
         for _ in range(2):
             run('K4 fwd NT', 50176, 1200, 2048, True, True, [(9, 1)])

@@ -891,26 +891,35 @@ k_gemm_bf16_pp(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__
         if (BKM) return frag_read<128, true>(q, r0, kk, lane);
         return pp_frag_m(qu, ml.X, r0, kk);
     };
-    auto sumsq = [&](const bf16x8_t& v, float s) {
-        s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(v, v, 0, 1), __builtin_shufflevector(v, v, 0, 1), s, false);
-        s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(v, v, 2, 3), __builtin_shufflevector(v, v, 2, 3), s, false);
-        s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(v, v, 4, 5), __builtin_shufflevector(v, v, 4, 5), s, false);
-        s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(v, v, 6, 7), __builtin_shufflevector(v, v, 6, 7), s, false);
-        return s;
-    };
-#define PP_MFMA(I0, FB, J0_)                                                                                    \
+    // NORM: the four column-waves that share 128 A rows take two of the eight 16-row fragments each (2 wn, 2 wn + 1):
+    // one per phase 0 / 1, read once more from LDS into `fn` (a register array cannot be indexed by the wave id, an LDS
+    // address can) and squared by one v_dot2 on a bf16 pair after every second MFMA of the cluster -- the MFMA holds the
+    // SIMD's vector issue for half of its 16 cycles, so a VALU instruction per gap rides along.  SQ = 0: no squares.
+#define PP_SQ(V, PR, ACC)                                                                                       \
+    ACC = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(V, V, 2 * (PR), 2 * (PR) + 1),                \
+                                          __builtin_shufflevector(V, V, 2 * (PR), 2 * (PR) + 1), ACC, false)
+#define PP_MFMA(I0, FB, J0_, SQ, S)                                                                             \
     do {                                                                                                        \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                                      \
         __builtin_amdgcn_s_setprio(1);                                                                          \
-        if (kCompute) _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                        \
+        if (kCompute) _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                          \
             _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                       \
-                _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                   \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                 \
                     acc[(I0) + i][(J0_) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB[kk][j], fa[kk][i],    \
                                                                                        acc[(I0) + i][(J0_) + j], 0, 0, 0); \
+                    if (NORM && (SQ) && j == 1) {               /* piece kk * 4 + i: K sub-step kk, pair i */   \
+                        if (i == 0) PP_SQ(fn[kk], 0, S[kk]);                                                    \
+                        if (i == 1) PP_SQ(fn[kk], 1, S[kk]);                                                    \
+                        if (i == 2) PP_SQ(fn[kk], 2, S[kk]);                                                    \
+                        if (i == 3) PP_SQ(fn[kk], 3, S[kk]);                                                    \
+                    }                                                                                           \
+                }                                                                                               \
         __builtin_amdgcn_s_setprio(0);                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                                      \
     } while (0)
+    float ssp[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    bf16x8_t fn[2];
 
     // prologue: tile 0 and three quarters of tile 1
     issue(0, J0{}); issue(1, J1{}); issue(2, J2{}); issue(3, J3{});
@@ -934,22 +943,20 @@ k_gemm_bf16_pp(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
             for (int i = 0; i < 4; ++i) if (kCompute) fa[kk][i] = read_a(la, lau, i * 16, kk);
+        if (NORM) { fn[0] = read_a(la, lau, 32 * wn, 0); fn[1] = read_a(la, lau, 32 * wn, 1); }
         issue(q0 + 7, J3{});
         __builtin_amdgcn_s_barrier();
-        PP_MFMA(0, fb0, 0);
-        if (NORM) {
-            if (wn == 0) { ss[0] = sumsq(fa[0][0], sumsq(fa[1][0], ss[0])); ss[1] = sumsq(fa[0][1], sumsq(fa[1][1], ss[1])); }
-            else if (wn == 1) { ss[0] = sumsq(fa[0][2], sumsq(fa[1][2], ss[0])); ss[1] = sumsq(fa[0][3], sumsq(fa[1][3], ss[1])); }
-        }
+        PP_MFMA(0, fb0, 0, 1, ssp[0]);
         __builtin_amdgcn_s_barrier();
         // ---- phase 1: B columns bc+32 .. bc+63 -> acc[0..3][2..3]
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
             for (int j = 0; j < 2; ++j) if (kCompute) fb1[kk][j] = read_b(lb, lbu, bc + 32 + j * 16, kk);
+        if (NORM) { fn[0] = read_a(la, lau, 32 * wn + 16, 0); fn[1] = read_a(la, lau, 32 * wn + 16, 1); }
         issue(q0 + 8, J0{});
         __builtin_amdgcn_s_barrier();
-        PP_MFMA(0, fb1, 2);
+        PP_MFMA(0, fb1, 2, 1, ssp[1]);
         __builtin_amdgcn_s_barrier();
         // ---- phase 2: A rows 64 .. 127 -> acc[4..7][2..3]
 #pragma unroll
@@ -958,19 +965,18 @@ k_gemm_bf16_pp(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__
             for (int i = 0; i < 4; ++i) if (kCompute) fa[kk][i] = read_a(la, lau, 64 + i * 16, kk);
         issue(q0 + 9, J1{});
         __builtin_amdgcn_s_barrier();
-        PP_MFMA(4, fb1, 2);
-        if (NORM) {
-            if (wn == 2) { ss[0] = sumsq(fa[0][0], sumsq(fa[1][0], ss[0])); ss[1] = sumsq(fa[0][1], sumsq(fa[1][1], ss[1])); }
-            else if (wn == 3) { ss[0] = sumsq(fa[0][2], sumsq(fa[1][2], ss[0])); ss[1] = sumsq(fa[0][3], sumsq(fa[1][3], ss[1])); }
-        }
+        PP_MFMA(4, fb1, 2, 0, ssp[0]);
         __builtin_amdgcn_s_barrier();
         // ---- phase 3: no reads (fb0 is still in registers) -> acc[4..7][0..1]; tile t+1 must have landed after it
         issue(q0 + 10, J2{});
         if (t + 2 < nk) { VMCNT_BARRIER(6); } else { VMCNT_BARRIER(0); }
-        PP_MFMA(4, fb0, 0);
+        PP_MFMA(4, fb0, 0, 0, ssp[0]);
         __builtin_amdgcn_s_barrier();
     }
 #undef PP_MFMA
+#undef PP_SQ
+    ss[0] = ssp[0][0] + ssp[0][1];
+    ss[1] = ssp[1][0] + ssp[1][1];
     if (wm == 0) __builtin_amdgcn_s_barrier();              // the barrier waves 4-7 took at the start
 #if defined(PP_PROBE) && PP_PROBE == 3
     {                                                        // probe build: no output stores (timing only)
