@@ -244,9 +244,9 @@ def main():
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'avg_launch_ms': k6_ms, 'timed_launches': k6_n,
                          'algorithmic_bytes_per_launch': k6_bytes},
-            'roofline_gemm': dict(gemms, bound='mfma', note='HIP events on the launch stream inside the timed region; the '
-                                  'question encoder runs on a second stream beside the projection, so its span includes '
-                                  'the CU time the encoder kernels took'),
+            'roofline_gemm': dict(gemms, bound='mfma', note='HIP events on the launch stream inside the timed region'
+                                  + ('; the question encoder runs on a second stream beside the projection, so its span '
+                                     'includes the CU time the encoder kernels took' if args.overlap_encoder else '')),
             'loss': float(loss),
         }
         if diag:
