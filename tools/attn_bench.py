@@ -3,7 +3,7 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from vqa_amd._lib import call, ptr, BF16
-B, R, A, Dv = int(os.environ.get('B', 256)), int(os.environ.get('R', 196)), 1200, 2048
+B, R, A, Dv = int(os.environ.get('B', 256)), int(os.environ.get('R', 196)), int(os.environ.get('A', 1200)), 2048
 n_rot = 3
 dt = torch.bfloat16
 g = torch.Generator(device='cuda').manual_seed(0)
