@@ -636,7 +636,7 @@ k_attn_fwd_online(const bf16_t* __restrict__ P, int ldP, const bf16_t* __restric
 
 // Backward, bf16, pipelined.  Same results layout as k_attn_bwd.  NVD = ceil(Dv / 512).
 // Phase C uses r = 1/(exp2(k (P+qa)) + 1):  t = 1 - 2r,  1 - t^2 = 4 r (1 - r).
-template <int NVD>
+template <int NVD, bool NTS>
 __global__ void __launch_bounds__(ATT_THREADS)
 k_attn_bwd_pipe(const bf16_t* __restrict__ P, int ldP, const bf16_t* __restrict__ V, int ldV,
                 const float* __restrict__ qa, int ld_qa, const float* __restrict__ w_a,
@@ -768,9 +768,11 @@ k_attn_bwd_pipe(const bf16_t* __restrict__ P, int ldP, const bf16_t* __restrict_
             u16x8 ov;
 #pragma unroll
             for (int e = 0; e < 8; ++e) ov[e] = f32_to_bf16(o[e]);
-            // (a cached store: the weight-gradient product that follows reads dP, and what of it is still in the
-            //  Infinity Cache arrives sooner than from HBM: -4 us per step against a non-temporal store)
-            *reinterpret_cast<u16x8*>(colD + (size_t)r * ld_dP) = ov;
+            // (a cached store while dP fits the Infinity Cache: the weight-gradient product that follows reads dP, and
+            //  what of it is still there arrives sooner than from HBM: -4 us per step at B = 256, R = 196 against a
+            //  non-temporal store; a larger dP is streamed past the caches)
+            if (NTS) __builtin_nontemporal_store(ov, reinterpret_cast<u16x8*>(colD + (size_t)r * ld_dP));
+            else *reinterpret_cast<u16x8*>(colD + (size_t)r * ld_dP) = ov;
         };
         // two batches of 4 rows in flight: the next batch is requested before the current one is consumed
         // (row indices clamped, so every load is unconditional; rows past R are not consumed)
@@ -934,15 +936,19 @@ static int attn_bwd_impl(const void* P, int ldP, const void* V, int ldV, const f
         d_slabs = nullptr;
     }
     if (pipe) {
-#define ATT_BWD_PIPE(NVD)                                                                                          \
+#define ATT_BWD_PIPE_(NVD, NTS)                                                                                    \
   {                                                                                                                \
     if (lds > 48 * 1024)                                                                                           \
-        VQA_REQUIRE(hipFuncSetAttribute((const void*)k_attn_bwd_pipe<NVD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess, "vqa_attn_bwd: cannot reserve LDS"); \
-    k_attn_bwd_pipe<NVD><<<B, ATT_THREADS, lds, stream>>>((const bf16_t*)P, ldP, (const bf16_t*)V, ldV, qa, ld_qa, w_a,  \
+        VQA_REQUIRE(hipFuncSetAttribute((const void*)k_attn_bwd_pipe<NVD, NTS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess, "vqa_attn_bwd: cannot reserve LDS"); \
+    k_attn_bwd_pipe<NVD, NTS><<<B, ATT_THREADS, lds, stream>>>((const bf16_t*)P, ldP, (const bf16_t*)V, ldV, qa, ld_qa, w_a,  \
         inv_norm, p_in, d_pooled, ld_dpool, (bf16_t*)dP, ld_dP, dqa_f32, (bf16_t*)dqa_t, ld_dqa, dwa_part, dc_part, R, A, Dv, \
         d_slabs, d_nslab, d_stride, d_seed, d_thr, d_scale); \
   }
+#define ATT_BWD_PIPE(NVD) { if (nts) ATT_BWD_PIPE_(NVD, true) else ATT_BWD_PIPE_(NVD, false) }
+        // dP larger than the Infinity Cache (256 MB) cannot wait there for the weight-gradient product
+        const bool nts = (size_t)B * R * ld_dP * 2 > ((size_t)192 << 20);
         if (nvd_l == 1) ATT_BWD_PIPE(1) else if (nvd_l == 2) ATT_BWD_PIPE(2) else if (nvd_l == 3) ATT_BWD_PIPE(3) else ATT_BWD_PIPE(4)
+#undef ATT_BWD_PIPE_
 #undef ATT_BWD_PIPE
         return vqa_check_launch("vqa_attn_bwd");
     }
