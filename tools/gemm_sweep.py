@@ -53,6 +53,24 @@ def run(name, M, N, K, akm, bkm, variants, ldb=None):
         us = timeit(lambda: call('vqa_gemm_slabs', ptr(A), lda, int(akm), ptr(Bm), ldb, int(bkm), ptr(slab), M * N, N, M, N, K, sk, 1, eng))
         print(f'{name:12s} M={M:6d} N={N:5d} K={K:6d} tile={ {2: "64", 3: "128", 4: "256x128", 6: "256x256", 8: "256x256r10", 9: "256x256r10pf", 10: "256x256pp"}[eng] } splitk={sk:2d}: {us:8.1f} us  {2.0 * M * N * K / us / 1e6:7.1f} TF')
 
+def run_pitch():
+    """Does the operand pitch matter (power-of-two row pitch = every row of a tile column on one memory channel)?"""
+    dt = torch.bfloat16
+    M, N, K = 50176, 1200, 2048
+    Bm = (torch.randn((N, K), device='cuda') * 0.05).to(dt)
+    slab = torch.empty(max(M * N, 6 * 2048 * 1200), device='cuda', dtype=torch.float32)   # fp32 output of either product
+    for _ in range(3):
+        for lda in (2048, 2048 + 64, 2048 + 128, 2048 + 512):
+            A = (torch.randn((M, lda), device='cuda') * 0.5).clamp_min_(0).to(dt)
+            us = timeit(lambda: call('vqa_gemm_slabs', ptr(A), lda, 1, ptr(Bm), K, 1, ptr(slab), M * N, N, M, N, K, 1, 1, 10))
+            print(f'proj k-major lda={lda}: {us:8.1f} us  {2.0 * M * N * K / us / 1e6:7.1f} TF')
+            # weight gradient: A = V as [K=50176][lda] (m-major), B = dP as [K][1280]
+            dP = (torch.randn((M, 1280), device='cuda') * 0.5).to(dt)
+            us = timeit(lambda: call('vqa_gemm_slabs', ptr(A), lda, 0, ptr(dP), 1280, 0, ptr(slab), 2048 * 1200, 1200, 2048, 1200, M, 6, 1, 10))
+            print(f'wgrad m-major lda={lda}: {us:8.1f} us  {2.0 * M * N * K / us / 1e6:7.1f} TF')
+            del A, dP
+
+
 if __name__ == '__main__':
     which = sys.argv[1] if len(sys.argv) > 1 else 'big'
     if which == 'big':
@@ -75,6 +93,8 @@ if __name__ == '__main__':
             run('K4 fwd NT', 50176, 1200, 2048, True, True, [(10, 1)])
             run('sq4k', 4096, 4096, 4096, True, True, [(10, 1)])
             run('square', 8192, 8192, 8192, True, True, [(10, 1)])
+    elif which == 'pitch':
+        run_pitch()
     elif which == 'wg':
         for _ in range(3):
             run('wgrad TN swapped', 2048, 1200, 50176, False, False, [(6, 6), (10, 6), (10, 5), (10, 7)])
