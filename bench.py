@@ -92,8 +92,9 @@ def main():
     ap.add_argument('--no-pad-rows', action='store_true', help='A/B: projected features P / dP with unpadded 2400-byte rows')
     ap.add_argument('--rccl-single', action='store_true',
                     help='N=1 only: run the bucketed all-reduce path over a one-rank RCCL group (its cost without peers)')
-    ap.add_argument('--event-stride', type=int, default=4,
-                    help='HIP-event pairs go around every n-th launch of the roofline kernel inside the timed region')
+    ap.add_argument('--event-stride', type=int, default=10,
+                    help='HIP-event pairs go around every n-th launch of the roofline kernels (and every n-th step of the '
+                         'gradient reducer) inside the timed region: an event record costs the stream about 10 us')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -146,6 +147,7 @@ def main():
     model.kernel_event_stride = args.event_stride
     if reducer is not None:
         reducer.timing = {}
+        reducer.timing_stride = max(args.event_stride, 1)
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = step(args.warmup + i)
@@ -177,12 +179,14 @@ def main():
         if reducer is not None and reducer.timing:
             launches = reducer.timing.get('launch', [])
             waits = reducer.timing.get('wait', [])
-            per_step = max(len(launches) // max(args.steps, 1), 1)
-            exposed = sum(a.elapsed_time(b) for a, b in waits) / max(args.steps, 1)
-            comm = {'collectives_per_step': per_step,
-                    'allreduce_bytes_per_step': sum(nby for nby, _ in launches) // max(args.steps, 1),
+            timed_steps = max((args.steps + reducer.timing_stride - 1) // reducer.timing_stride, 1)
+            per_step = max(len(launches) // timed_steps, 1)
+            exposed = sum(a.elapsed_time(b) for a, b in waits) / timed_steps
+            comm = {'timed_steps': timed_steps,
+                    'collectives_per_step': per_step,
+                    'allreduce_bytes_per_step': sum(nby for nby, _ in launches) // timed_steps,
                     'bytes_of_each_collective': [nby for nby, _ in launches[:per_step]],
-                    'waits_per_step': len(waits) / max(args.steps, 1),
+                    'waits_per_step': len(waits) / timed_steps,
                     'exposed_wait_ms_per_step': exposed,
                     'note': 'exposed_wait = HIP-event time the compute stream spent in cross-stream waits for the '
                             'collectives (everything else of them ran under backward / the next forward)'}

@@ -1,7 +1,7 @@
 """Prints the kernel timeline of the last full train step found in a rocprofv3 kernel trace (csv)."""
 import csv, glob, sys, os
 d = sys.argv[1]
-f = glob.glob(os.path.join(d, '**', '*kernel_trace.csv'), recursive=True)[0]
+f = max(glob.glob(os.path.join(d, '**', '*kernel_trace.csv'), recursive=True), key=os.path.getmtime)   # newest run
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
 marks = [i for i, r in enumerate(rows) if 'k_sequence_pack' in r['Kernel_Name']]
 a, b = marks[-2], marks[-1]

@@ -52,7 +52,12 @@ class GradReducer:
         # timing (switched on by setting `timing = {}`): per collective the bytes and an event on the compute stream
         # at its launch; per wait an event pair on the compute stream around the cross-stream wait.  The wait pair is
         # the communication the compute stream could not hide; launch -> end of the wait bounds the collective's span.
+        # An event record costs the stream about 10 us of idle time, so only every `timing_stride`-th pass is timed
+        # (its launches, and the wait that completes them, which may sit in the next step).
         self.timing: Optional[dict] = None
+        self.timing_stride = 1
+        self._pass = -1
+        self._timed = False
 
     def begin(self, model) -> None:
         """Bind to the model's flat gradient buffer for one backward pass."""
@@ -63,10 +68,12 @@ class GradReducer:
         self._last_handle = None
         self._next, self._run = 0, None
         self.launched = []
+        self._pass += 1
+        self._timed = self.timing is not None and self._pass % max(int(self.timing_stride), 1) == 0
 
     def _launch(self, s: int, e: int):
         self.launched.append((s, e))
-        if self.timing is not None:
+        if self._timed and self.timing is not None:
             ev = torch.cuda.Event(enable_timing=True)
             ev.record()
             self.timing.setdefault('launch', []).append((4 * (e - s), ev))
@@ -124,7 +131,7 @@ class GradReducer:
         if not handles:
             return
         pair = None
-        if self.timing is not None:
+        if self._timed and self.timing is not None:
             pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             pair[0].record()
         if self._in_order:
