@@ -121,3 +121,38 @@ def test_out_of_range_ids_raise_at_the_next_sync():
     m2.train_step(f, t, bad_a)
     with pytest.raises(IndexError, match='Target out of bounds'):
         m2.sync()
+
+
+@pytest.mark.parametrize('arch', ['lstm', '2-lstm'])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_one_and_two_token_questions(arch, dtype):
+    """Questions of one, two and three token slots (the tabulated first two steps of the frozen encoder have nothing
+    or one step after them), with an all-pad row and a row of length 1, through the encoder and the whole forward,
+    with and without the per-token tables (seq2vec.py:11-25, 40-45)."""
+    from oracle import vqa_ref
+    from vqa_amd.model import VQAAttnModel
+    kw = dict(vq=50, C=11, E=20, Hq=48, Dv=64, A=16, F=16, Hf=8)
+    p = vqa_ref.init_params(seed=3, two_lstm=(arch == '2-lstm'), **kw)
+    m = VQAAttnModel(['w'] * kw['vq'], ['a'] * kw['C'], None, dtype=dtype, emb_size=kw['E'], question_out=kw['Hq'],
+                     visual_out=kw['Dv'], attention_dim=kw['A'], fusion_in=kw['F'], fusion_hidden=kw['Hf'], seed=1,
+                     seq2vec_arch=arch)
+    m.load_state_dict(p)
+    m = m.to('cuda').eval()
+    po = p if dtype == torch.float32 else {k: v.to(torch.bfloat16).float() for k, v in p.items()}
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    for L in (1, 2, 3):
+        g = torch.Generator().manual_seed(L)
+        tok = torch.randint(1, kw['vq'], (9, L), generator=g)
+        tok[2] = 0
+        if L > 1:
+            tok[4, 1:] = 0
+        ref = vqa_ref.encode_question(tok, po)
+        for fold in (True, False):
+            m.fold_embedding = m.fold_first_step = fold
+            q = m.encode_question(tok.cuda()).cpu()
+            assert float((q - ref).abs().max()) <= tol * float(ref.abs().max()), (L, fold)
+        feats = torch.randn(9, 5, kw['Dv'], generator=g).clamp_min(0).to(dtype)
+        with torch.no_grad():
+            out = m(feats.cuda(), tok.cuda()).float().cpu()
+        want, _, _ = vqa_ref.loss_and_grads(po, feats.float(), tok, torch.zeros(9, dtype=torch.long), None, 1)
+        assert float((out - want).abs().max()) <= tol * float(want.abs().max()), L
