@@ -89,6 +89,8 @@ def main():
     ap.add_argument('--no-swap-wgrad', action='store_true', help='A/B: dW_va in the nn.Linear orientation')
     ap.add_argument('--fused-lstm-step', action='store_true', help='A/B: recurrent product and cell update of an LSTM step in one launch')
     ap.add_argument('--overlap-encoder', action='store_true', help='A/B: frozen question encoder on a second stream beside the region projection')
+    ap.add_argument('--no-merge-head', action='store_true',
+                    help="A/B: the head's weight / bias gradients in a launch of their own instead of the attention backward's")
     ap.add_argument('--no-pad-rows', action='store_true', help='A/B: projected features P / dP with unpadded 2400-byte rows')
     ap.add_argument('--rccl-single', action='store_true',
                     help='N=1 only: run the bucketed all-reduce path over a one-rank RCCL group (its cost without peers)')
@@ -128,6 +130,8 @@ def main():
         model.overlap_encoder = True
     if args.no_pad_rows:
         model.pad_projection_rows = False
+    if args.no_merge_head:
+        model.merge_head_group = False
     reducer = GradReducer(force=args.rccl_single) if (world > 1 or args.rccl_single) else None
     nb = max(2, min(4, (320 << 20) // (B * R * Dv * 2) + 1))      # > 256 MiB of features in rotation
     batches = synth_batches(nb, B, R, Dv, L, Vq, C, dev, 42 + rank, torch.bfloat16)

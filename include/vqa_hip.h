@@ -252,7 +252,7 @@ int vqa_gemm_splitk_hint(int M, int N, int K, int a_kmajor, int b_kmajor);
 int vqa_gemm_slabs(const void* A, int lda, int a_kmajor, const void* B, int ldb, int b_kmajor, float* slabs,
                    size_t slab_stride, int ld_slab, int M, int N, int K, int splitk, int dtype, int engine,
                    hipStream_t stream);
-/* Up to 4 independent products of the same operand layout in one launch (each product of the head is a few
+/* Up to 8 independent products of the same operand layout in one launch (each product of the head is a few
  * microseconds of work and a dependent launch costs about as much): slabs as above, 64 x 64 tiles for bf16;
  * fp32 runs them one after the other. */
 typedef struct {

@@ -263,7 +263,7 @@ k_gemm_bf16(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B,
 
 // Several independent small products (64 x 64 tiles, fp32 partial sums) in one launch: each product costs a
 // dependent launch about 4.5 us whatever its size, and small ones do not fill the chip on their own.
-#define VQA_GEMM_GROUP_MAX 4
+#define VQA_GEMM_GROUP_MAX 8
 struct GemmGroup {
     const bf16_t* A[VQA_GEMM_GROUP_MAX]; const bf16_t* B[VQA_GEMM_GROUP_MAX]; float* out[VQA_GEMM_GROUP_MAX];
     size_t split_stride[VQA_GEMM_GROUP_MAX];
@@ -1247,7 +1247,7 @@ int vqa_gemm_slabs_group_colsum(const VqaGemmDesc* descs, int n, int a_kmajor, i
 
 static int gemm_group_impl(const VqaGemmDesc* descs, int n, int a_kmajor, int b_kmajor, int dtype,
                            const VqaColsumDesc* cdescs, int nc, hipStream_t stream) {
-    VQA_REQUIRE(descs && n >= 1 && n <= VQA_GEMM_GROUP_MAX, "vqa_gemm_slabs_group: 1..4 products");
+    VQA_REQUIRE(descs && n >= 1 && n <= VQA_GEMM_GROUP_MAX, "vqa_gemm_slabs_group: 1..8 products");
     bool mfma = dtype == VQA_BF16;
     for (int i = 0; i < n; ++i) {
         const VqaGemmDesc& d = descs[i];

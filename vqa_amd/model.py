@@ -207,6 +207,7 @@ class _VQAHeadModel(nn.Module):
         self._bptt = False            # the running forward keeps the encoder state for backward through time
         self._loss_pending = False    # the mean of the per-row losses is still to be reduced (by backward)
         self._wslab, self._wslab_off, self._wgrad_pending = None, 0, []
+        self._held_group = None       # the head's weight / bias gradient problems waiting for the front end's launch
 
     # ------------------------------------------------------------------ flat parameter storage
     def _trainable_order(self) -> List[Tuple[str, nn.Parameter]]:
@@ -483,7 +484,7 @@ class _VQAHeadModel(nn.Module):
         """Several weight gradients (dy, ld_dy, x, ldx, wname, M, N, K), each grad(W)[M,N] = dy^T x, as one launch
         when their contraction is short; a product with one K range is written straight into the gradient buffer,
         the others leave partial sums for _flush_wgrads()."""
-        if self.dt != _lib.BF16 or any(K > 512 for *_, K in items) or len(items) > 4:
+        if self.dt != _lib.BF16 or any(K > 512 for *_, K in items) or len(items) > 8:
             if colsums:
                 _lib.colsum_multi(colsums)
             for dy, ld_dy, x, ldx, wname, M, N, K in items:
@@ -848,13 +849,19 @@ class _VQAHeadModel(nn.Module):
                              (ws['dz1'], Hf, B, Hf, dt, g('linear_classif1.bias'), None),
                              (ws['dzv'], F, B, F, dt, g('linear_v.bias'), None),
                              (ws['dzq'], F, B, F, dt, g('linear_q.bias'), None)]
-        self._wgrad_grouped([(ws['dlogits'], Cp, ws['h1d'], Hf, 'linear_classif2.weight', C, Hf, B),
-                             (ws['dz1'], Hf, ws['x'], F + Ec, 'linear_classif1.weight', Hf, F + Ec, B),
-                             (ws['dzv'], F, ws['pooled_d'], Dv, 'linear_v.weight', F, Dv, B),
-                             (ws['dzq'], F, ws['q_d'], H, 'linear_q.weight', F, H, B)],
-                            colsums=head_bias)                 # the head's four weight and bias gradients: one launch
-        self._flush_wgrads()                      # (those with split K: partial sums reduced in one launch)
-        self._bucket_done('linear_q.bias')
+        head_items = [(ws['dlogits'], Cp, ws['h1d'], Hf, 'linear_classif2.weight', C, Hf, B),
+                      (ws['dz1'], Hf, ws['x'], F + Ec, 'linear_classif1.weight', Hf, F + Ec, B),
+                      (ws['dzv'], F, ws['pooled_d'], Dv, 'linear_v.weight', F, Dv, B),
+                      (ws['dzq'], F, ws['q_d'], H, 'linear_q.weight', F, H, B)]
+        if self._takes_head_group(B):
+            # nothing downstream reads these gradients: the front end's backward launches them together with its own
+            # small ones (one dependent launch less on the way to its first big kernel)
+            self._held_group = (head_items, head_bias)
+        else:
+            self._held_group = None
+            self._wgrad_grouped(head_items, colsums=head_bias)     # the head's four weight and bias gradients: one launch
+            self._flush_wgrads()                  # (those with split K: partial sums reduced in one launch)
+            self._bucket_done('linear_q.bias')
         slab, sk, st = self._gemm_slabs(ws['dzv'], F, 1, self._w('linear_v.weight'), Dv, 0, B, Dv, F)
         if self._dpool_from_slabs and not self.train_encoder:
             # the attention backward kernel reduces these partial sums (and applies dropoutV's mask) in its prologue;
@@ -871,6 +878,11 @@ class _VQAHeadModel(nn.Module):
         self._visual_backward(ws, feats, B)
         if self.train_encoder:
             self._encoder_backward(ws, B, L, seeds)
+
+    def _takes_head_group(self, B) -> bool:
+        """True when _visual_backward() launches the head's held weight / bias gradients (self._held_group) with its
+        own first group of small gradients and then signals the head's bucket."""
+        return False
 
     def _add_dq(self, ws, B, slab, sk, st):
         """dq += sum of the slabs (a front-end's contribution to d loss / d q)."""
@@ -1126,6 +1138,13 @@ class VQAAttnModel(_VQAHeadModel):
             out += [f'attention.{k}.linear_a.weight', f'attention.{k}.linear_va.weight']
         return out
 
+    # the head's weight / bias gradients ride in the launch of the last hop's small gradients (bf16; the grouped
+    # launch takes contractions up to 512 rows and 8 column sums)
+    merge_head_group = True
+
+    def _takes_head_group(self, B) -> bool:
+        return self.merge_head_group and self.dt == _lib.BF16 and B <= 512
+
     def _q_side_products(self, ws):
         # the first hop's query projection reads the question vector itself
         return super()._q_side_products(ws) + [('qa0', ws['qT'], self.Hq, 'attention.0.linear_qa.weight', self.A, self.Hq)]
@@ -1257,12 +1276,19 @@ class VQAAttnModel(_VQAHeadModel):
                      ptr(self._f32(pre + 'linear_a.weight')), ptr(ws['inv_norm']), ptr(ws[f'p{k}']), ptr(ws['d_pooled']), Dv,
                      ptr(ws['dP']), ldA, ptr(ws['dqa32']), ptr(ws['dqaT']), A, ptr(ws['dwa_part']), ptr(ws['dc_part']),
                      B, R, A, Dv, dt)
-            # the hop's small gradients in one launch: w_a, its offset c, and the two biases that share d(P + qa)
-            self._wgrad_grouped([(ws['dqaT'], A, uT, H, pre + 'linear_qa.weight', A, H, B)],
-                                colsums=[(ws['dwa_part'], A, B, A, _lib.F32, g(pre + 'linear_a.weight'), None),
-                                         (ws['dc_part'], 1, B, 1, _lib.F32, g(pre + 'linear_a.bias'), None),
-                                         (ws['dqa32'], A, B, A, _lib.F32, g(pre + 'linear_qa.bias'), g(pre + 'linear_va.bias'))])
+            # the hop's small gradients in one launch: w_a, its offset c, and the two biases that share d(P + qa);
+            # the last hop's launch (the first one here) also carries the head's held weight and bias gradients
+            items = [(ws['dqaT'], A, uT, H, pre + 'linear_qa.weight', A, H, B)]
+            colsums = [(ws['dwa_part'], A, B, A, _lib.F32, g(pre + 'linear_a.weight'), None),
+                       (ws['dc_part'], 1, B, 1, _lib.F32, g(pre + 'linear_a.bias'), None),
+                       (ws['dqa32'], A, B, A, _lib.F32, g(pre + 'linear_qa.bias'), g(pre + 'linear_va.bias'))]
+            held, self._held_group = self._held_group, None
+            if held is not None:
+                items, colsums = held[0] + items, held[1] + colsums
+            self._wgrad_grouped(items, colsums=colsums)
             self._flush_wgrads()
+            if held is not None:
+                self._bucket_done('linear_q.bias')
             if k > 0:
                 ppre = f'attention.{k - 1}.'
                 slab, sk, st = self._gemm_slabs(ws['dqaT'], A, 1, self._w(pre + 'linear_qa.weight'), H, 0, B, H, A)
