@@ -151,9 +151,10 @@ def test_projection_with_fused_row_norm(M, N, K, out_dtype):
 
 @pytest.mark.parametrize('akm,bkm', [(1, 1), (0, 0), (1, 0)])
 def test_grouped_small_products(akm, bkm):
-    """Up to four independent products in one launch give exactly what the single launches give (64 x 64 tiles)."""
+    """Up to eight independent products in one launch give exactly what the single launches give (64 x 64 tiles)."""
     from vqa_amd import _lib
-    shapes = [(256, 1200, 2400, 6), (256, 1208, 2400, 6), (37, 50, 72, 1), (300, 129, 64, 3)]
+    shapes = [(256, 1200, 2400, 6), (256, 1208, 2400, 6), (37, 50, 72, 1), (300, 129, 64, 3),
+              (3000, 256, 256, 1), (256, 1200, 256, 1), (1200, 2048, 256, 1), (64, 8, 512, 2)]
     ops, problems, singles = [], [], []
     for i, (M, N, K, sk) in enumerate(shapes):
         As, lda, Bs, ldb, ref = make(M, N, K, akm, bkm, torch.bfloat16, 40 + i)
@@ -162,7 +163,7 @@ def test_grouped_small_products(akm, bkm):
         call('vqa_gemm_slabs', ptr(As), lda, akm, ptr(Bs), ldb, bkm, ptr(single), M * N, N, M, N, K, sk, BF16, 2)
         problems.append((ptr(As), lda, ptr(Bs), ldb, ptr(grouped), M * N, N, M, N, K, sk))
         ops.append((As, Bs, ref, grouped, single))
-    for n in (4, 1, 3):
+    for n in (8, 4, 1, 3):
         for _, _, _, grouped, _ in ops:
             grouped.fill_(float('nan'))
         _lib.gemm_slabs_group(problems[:n], akm, bkm, BF16)
