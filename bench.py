@@ -148,10 +148,12 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     model.kernel_events = {}
-    model.kernel_event_stride = args.event_stride
+    # (short runs sample more densely: at least about eight timed launches of each kernel)
+    stride = max(1, min(args.event_stride, args.steps // 8))
+    model.kernel_event_stride = stride
     if reducer is not None:
         reducer.timing = {}
-        reducer.timing_stride = max(args.event_stride, 1)
+        reducer.timing_stride = stride
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = step(args.warmup + i)
