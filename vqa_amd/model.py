@@ -991,11 +991,13 @@ class _VQAHeadModel(nn.Module):
         reducer.finish_last()
         self._adam_range(lo, hi, lr, betas, eps, step, scale)
 
-    def sync(self):
+    def sync(self, check: bool = True):
         """Make every parameter current (applies a deferred last-bucket update, if any) and raise for inputs the
-        kernels flagged since the last check."""
+        kernels flagged since the last check.  check=False only enqueues the deferred update (no read-back of the
+        status words, which waits for the stream): call check_status() later."""
         self._finish_pending()
-        self.check_status()
+        if check:
+            self.check_status()
 
     def _status_words(self, device) -> torch.Tensor:
         st = getattr(self, '_status', None)
