@@ -9,8 +9,6 @@ B, R, Dv, L, Vq, C = 256, 196, 2048, 14, 10000, 3000
 m = VQAAttnModel(['w'] * Vq, ['a'] * C, None, dtype=torch.bfloat16).to(dev).train()
 batches = bench.synth_batches(3, B, R, Dv, L, Vq, C, dev, 42, torch.bfloat16)
 W = int(sys.argv[1]) if len(sys.argv) > 1 else 5
-if len(sys.argv) > 2 and sys.argv[2] == "encoder_first":
-    m.visual_first = False
 for i in range(W): m.train_step(*batches[i % 3])
 m.sync(); torch.cuda.synchronize()
 evs = [torch.cuda.Event(enable_timing=True) for _ in range(41)]
