@@ -11,7 +11,6 @@ batches in rotation so that the 256 MiB Infinity Cache cannot hold the inputs).
 Dropout is on (training mode).  Rank 0 prints one JSON line.
 """
 import argparse
-import gc
 import json
 import os
 import sys
@@ -155,8 +154,6 @@ def main():
     if reducer is not None:
         reducer.timing = {}
         reducer.timing_stride = stride
-    gc.collect()
-    gc.disable()                      # no collector pause on the launching thread inside the timed region
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = step(args.warmup + i)
@@ -166,7 +163,6 @@ def main():
         dist.barrier()
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    gc.enable()
     model.check_status()              # (the read-back of the kernels' status words is not part of a step)
     my_elapsed_local = elapsed
     if world > 1:
