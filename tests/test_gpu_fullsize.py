@@ -215,3 +215,21 @@ def test_cfg2_fast_paths_agree_with_plain_paths(full_model):
         num = float((ga[k] - gb[k]).norm())
         den = float(gb[k].norm())
         assert num <= 2e-2 * den + 1e-12, (k, num, den)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_gap_model_reference_widths(dtype):
+    """VQAGAPModel at the reference's own widths (model.py:81-184: ResNet-152 stage maps of a 512-pixel image,
+    256 / 512 / 1024 / 2048 channels on 128 / 64 / 32 / 16 grids, VISUAL_OUT_GAP = 3840, QUESTION_OUT = 2400,
+    FUSION_IN = 1200, FUSION_HIDDEN = 256), channels-last maps, evaluation and training mode, against the oracle."""
+    from tests.test_gpu_frontends import _gap_model, _check
+    kw = dict(vq=300, C=95, E=620, Hq=2400, Dv=3840, A=8, F=1200, Hf=256)
+    channels, grids, B = (256, 512, 1024, 2048), (128, 64, 32, 16), 5
+    m, p = _gap_model(kw, channels, dtype)
+    maps = [x.to(dtype) for x in vqa_ref.synthetic_maps(B, channels, grids, seed=4)]
+    b = vqa_ref.synthetic_batch(B, 4, 8, 14, kw['vq'], kw['C'], seed=6)
+    po = p if dtype == torch.float32 else {k: v.to(torch.bfloat16).float() for k, v in p.items()}
+    gpu_maps = [x.cuda().contiguous(memory_format=torch.channels_last) for x in maps]
+    ref_maps = [x.float() for x in maps]
+    _check(m, po, ref_maps, gpu_maps, b, 'gap', dtype, train=False)
+    _check(m, po, ref_maps, gpu_maps, b, 'gap', dtype, train=True)
