@@ -233,3 +233,47 @@ def test_gap_model_reference_widths(dtype):
     ref_maps = [x.float() for x in maps]
     _check(m, po, ref_maps, gpu_maps, b, 'gap', dtype, train=False)
     _check(m, po, ref_maps, gpu_maps, b, 'gap', dtype, train=True)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_conv_model_reference_widths(dtype):
+    """VQAModel at the reference's widths (model.py:29-79): the last ResNet map of a 512-pixel image (2048 channels on a
+    16 x 16 grid), the 1 x 1 convolution down to VISUAL_OUT / 256 = 8 channels, NCHW flatten to VISUAL_OUT = 2048."""
+    from tests.test_gpu_frontends import _check
+    from vqa_amd.model import VQAModel
+    kw = dict(vq=300, C=95, E=620, Hq=2400, Dv=2048, A=8, F=1200, Hf=256)
+    input_size, B, Cin = 512, 6, 2048
+    g = input_size // 32
+    c_out = kw['Dv'] // (g * g)
+    p = vqa_ref.init_params(seed=3, mode='conv', conv_out=c_out, **{**kw, 'Dv': Cin})
+    p['linear_v.weight'] = vqa_ref.init_params(seed=4, **kw)['linear_v.weight']
+    m = VQAModel(['w'] * kw['vq'], ['a'] * kw['C'], None, input_size, dtype=dtype, emb_size=kw['E'],
+                 question_out=kw['Hq'], visual_out=kw['Dv'], fusion_in=kw['F'], fusion_hidden=kw['Hf'],
+                 map_channels=Cin, seed=1234)
+    m.load_state_dict(p)
+    m = m.to('cuda')
+    fmap = vqa_ref.synthetic_maps(B, (Cin,), (g,), seed=11)[0].to(dtype)
+    b = vqa_ref.synthetic_batch(B, 4, 8, 14, kw['vq'], kw['C'], seed=6)
+    po = p if dtype == torch.float32 else {k: v.to(torch.bfloat16).float() for k, v in p.items()}
+    _check(m, po, fmap.float(), fmap.cuda(), b, 'conv', dtype, train=False)
+    _check(m, po, fmap.float(), fmap.cuda(), b, 'conv', dtype, train=True)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_stack_model_reference_widths(dtype):
+    """The max / mean stack model (model.py:1234-1241) on the four ResNet-152 stage maps of a 512-pixel image with a
+    2048-wide stack."""
+    from tests.test_gpu_frontends import _check
+    from vqa_amd.model import VQAGAPStackModel
+    kw = dict(vq=300, C=95, E=620, Hq=2400, Dv=2048, A=8, F=1200, Hf=256)
+    channels, grids, B = (256, 512, 1024, 2048), (128, 64, 32, 16), 5
+    p = vqa_ref.init_params(seed=3, mode='stack', gap_channels=channels, **kw)
+    m = VQAGAPStackModel(['w'] * kw['vq'], ['a'] * kw['C'], None, dtype=dtype, emb_size=kw['E'], question_out=kw['Hq'],
+                         fusion_in=kw['F'], fusion_hidden=kw['Hf'], gap_channels=channels, stack_dim=kw['Dv'], seed=1234)
+    m.load_state_dict(p)
+    m = m.to('cuda')
+    maps = [x.to(dtype) for x in vqa_ref.synthetic_maps(B, channels, grids, seed=9)]
+    b = vqa_ref.synthetic_batch(B, 4, 8, 14, kw['vq'], kw['C'], seed=5)
+    po = p if dtype == torch.float32 else {k: v.to(torch.bfloat16).float() for k, v in p.items()}
+    _check(m, po, [x.float() for x in maps], [x.cuda() for x in maps], b, 'stack', dtype, train=False)
+    _check(m, po, [x.float() for x in maps], [x.cuda() for x in maps], b, 'stack', dtype, train=True)
