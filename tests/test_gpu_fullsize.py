@@ -277,3 +277,39 @@ def test_stack_model_reference_widths(dtype):
     po = p if dtype == torch.float32 else {k: v.to(torch.bfloat16).float() for k, v in p.items()}
     _check(m, po, [x.float() for x in maps], [x.cuda() for x in maps], b, 'stack', dtype, train=False)
     _check(m, po, [x.float() for x in maps], [x.cuda() for x in maps], b, 'stack', dtype, train=True)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_two_lstm_encoder_reference_widths(dtype):
+    """The attention model with the 2-lstm question encoder (seq2vec.py:48-76) at full width (two stacked layers of
+    1200, dropout 0.3 on each vector), evaluation and training mode, logits and every gradient against the oracle."""
+    from tests.test_gpu_model import rel_err, oracle_params_as
+    from vqa_amd.model import VQAAttnModel
+    kw = dict(vq=500, C=300, E=620, Hq=2400, Dv=2048, A=1200, F=1200, Hf=256)
+    p = vqa_ref.init_params(seed=3, two_lstm=True, **kw)
+    m = VQAAttnModel(['w'] * kw['vq'], ['a'] * kw['C'], None, dtype=dtype, emb_size=kw['E'], question_out=kw['Hq'],
+                     visual_out=kw['Dv'], attention_dim=kw['A'], fusion_in=kw['F'], fusion_hidden=kw['Hf'],
+                     seed=1234, seq2vec_arch='2-lstm')
+    m.load_state_dict(p)
+    m = m.to('cuda')
+    b = vqa_ref.synthetic_batch(12, 49, kw['Dv'], 14, kw['vq'], kw['C'], seed=5)
+    b['tokens'][3] = 0
+    feats = b['feats'].to(dtype)
+    po = oracle_params_as(p, dtype)
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    for train in (False, True):
+        m.train(train)
+        seeds = [vqa_ref.site_seed(1234, m.drop_step + 1, s) for s in range(6)] if train else None
+        logits_ref, _, grads_ref = vqa_ref.loss_and_grads(po, feats.float(), b['tokens'], b['answers'], None, 1, drop_seeds=seeds)
+        _, _, grads64 = vqa_ref.loss_and_grads({k: v.double() for k, v in po.items()}, feats.double(), b['tokens'],
+                                               b['answers'], None, 1, drop_seeds=seeds)
+        logits = m(feats.cuda(), b['tokens'].cuda())
+        assert rel_err(logits, logits_ref) <= tol
+        m.zero_grad()
+        torch.nn.functional.cross_entropy(logits.float(), b['answers'].cuda()).backward()
+        named = dict(m.named_parameters())
+        for k, gref in grads_ref.items():
+            if k.endswith('linear_a.bias'):
+                continue
+            noise = rel_err(gref, grads64[k])
+            assert rel_err(named[k].grad, grads64[k]) <= max(2 * tol, 4 * noise), (k, train, rel_err(named[k].grad, grads64[k]), noise)
