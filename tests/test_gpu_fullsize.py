@@ -313,3 +313,18 @@ def test_two_lstm_encoder_reference_widths(dtype):
                 continue
             noise = rel_err(gref, grads64[k])
             assert rel_err(named[k].grad, grads64[k]) <= max(2 * tol, 4 * noise), (k, train, rel_err(named[k].grad, grads64[k]), noise)
+
+
+@pytest.mark.parametrize('dtype,two', [(torch.float32, False), (torch.bfloat16, False), (torch.bfloat16, True)])
+def test_trainable_encoder_reference_widths(dtype, two):
+    """Backward through time at full width (E = 620, 2400 hidden units; the 2-lstm encoder as two layers of 1200):
+    every gradient, the embedding table's included, against the oracle's autograd, evaluation and training mode."""
+    from tests.test_gpu_encoder_train import _model, _batch, _compare
+    from vqa_amd.model import VQAAttnModel
+    kw = dict(vq=200, C=95, E=620, Hq=2400, Dv=2048, A=1200, F=1200, Hf=256)
+    m, p = _model(VQAAttnModel, kw, dtype, two, visual_out=kw['Dv'], attention_dim=kw['A'], hops=1)
+    b = _batch(kw, 10, 16, 14, seed=5)
+    feats = b['feats'].to(dtype)
+    po = p if dtype == torch.float32 else {k: v.to(torch.bfloat16).float() for k, v in p.items()}
+    _compare(m, po, feats.float(), feats.cuda(), b, dtype, train=False)
+    _compare(m, po, feats.float(), feats.cuda(), b, dtype, train=True)
