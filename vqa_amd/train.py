@@ -74,6 +74,9 @@ def train(model, train_dataset, validate_dataset, num_epochs, learning_rate, arg
     """resume: a TrainState_<model>.pth written by an earlier call (weights, Adam moments, epoch)."""
     meter = AccuracyMeter(HR_TYPES, device=next(model.parameters()).device)
     reducer = GradReducer()
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        # data-parallel ranks share the weights' seed but must not share dropout masks (they hash the local row)
+        model.dropout_rank = torch.distributed.get_rank()
     min_val, best_epoch, history, first_epoch = float('inf'), 0, [], 0
     if resume:
         st = torch.load(resume, weights_only=True)
