@@ -87,7 +87,6 @@ def main():
                     help='A/B: gather embeddings and run the LSTM input projection every step instead of the per-token table')
     ap.add_argument('--no-fold-first-step', action='store_true', help='A/B: run the recurrent product of step 1 as a GEMM')
     ap.add_argument('--no-swap-wgrad', action='store_true', help='A/B: dW_va in the nn.Linear orientation')
-    ap.add_argument('--fused-lstm-step', action='store_true', help='A/B: recurrent product and cell update of an LSTM step in one launch')
     ap.add_argument('--overlap-encoder', action='store_true', help='A/B: frozen question encoder on a second stream beside the region projection')
     ap.add_argument('--no-merge-head', action='store_true',
                     help="A/B: the head's weight / bias gradients in a launch of their own instead of the attention backward's")
@@ -124,8 +123,6 @@ def main():
         model.fold_first_step = False
     if args.no_swap_wgrad:
         model.swap_big_wgrad = False
-    if args.fused_lstm_step:
-        model.fused_lstm_step = True
     if args.overlap_encoder:
         model.overlap_encoder = True
     if args.no_pad_rows:

@@ -36,7 +36,10 @@ typedef struct ihipStream_t* hipStream_t;
 extern "C" {
 #endif
 
-#define VQA_HIP_VERSION 100
+/* 200: vqa_sequence_pack (+n_table_rows, status), vqa_softmax_ce (+status) and vqa_adam_step (+status) take more
+ * arguments than in version 100, and vqa_gemm_slabs_group takes up to 8 products: code built against the version-100
+ * header must be rebuilt (vqa_version() tells which library is loaded). */
+#define VQA_HIP_VERSION 200
 #define VQA_F32 0
 #define VQA_BF16 1
 
@@ -45,7 +48,8 @@ extern "C" {
  * it next synchronises anyway. */
 #define VQA_STATUS_BAD_TOKEN 0     /* a question token id outside the embedding table (nn.Embedding raises IndexError) */
 #define VQA_STATUS_BAD_TARGET 1    /* an answer id outside [0, C) (CrossEntropyLoss raises "Target out of bounds") */
-#define VQA_STATUS_WORDS 2
+#define VQA_STATUS_SKIPPED_STEP 2  /* vqa_adam_step: the `step` of the first update it skipped because BAD_TARGET was set */
+#define VQA_STATUS_WORDS 3
 
 int vqa_version(void);
 const char* vqa_last_error_string(void);
@@ -121,18 +125,6 @@ int vqa_lstm_cell01_table(const void* xg_table, int ld_xg, const float* hh_table
                           int B, int H, int L, const int32_t* perm, const int32_t* active, const int32_t* offsets,
                           void* hs, int ld_hs, void* q_drop, unsigned drop_seed, float drop_p, int dtype,
                           hipStream_t stream);
-
-/* One whole step t >= 1 on packed sequences in one launch (bf16 storage): the recurrent product h_{t-1} W_hh^T on the
- * matrix cores with vqa_lstm_cell_packed[_table] as its epilogue (a workgroup owns 128 rows x 16 hidden units and all
- * four gates of them, over the whole contraction: no partial sums, no second launch).  xg: the packed input
- * projections (tokens == NULL, row offsets[t] + j) or the per-token table (tokens given, n_table_rows rows).
- * h_prev (B, ld_h) holds the previous step's outputs in sorted row order; h_out must be a different buffer.
- * H % 16 == 0.  No state is saved for backward through time.          seq2vec.py:38, 43 (nn.LSTM), 16-25 */
-int vqa_lstm_step(const void* h_prev, int ld_h, const void* w_hh, int ld_w, const void* xg, int ld_xg,
-                  int n_table_rows, const int64_t* tokens, float* c, void* h_out, int ld_ho,
-                  const int32_t* lengths, float* q_f32, void* q_t, int ld_q, int B, int H, int t, int L,
-                  const int32_t* perm, const int32_t* active, const int32_t* offsets, void* hs, int ld_hs,
-                  void* q_drop, unsigned drop_seed, float drop_p, int dtype, hipStream_t stream);
 
 /* Backward through LSTM step t on packed sequences (a trainable question encoder; the reference
  * freezes it, model.py:42-43, so this has no counterpart there beyond autograd of seq2vec.py:43):
@@ -356,8 +348,10 @@ int vqa_cast_pad(const float* src, int ld_src, void* dst, int ld_dst, int M, int
  *                             train.py:35, 201 (CrossEntropyLoss) and 203 (backward) */
 int vqa_softmax_ce(const float* logits, int ld, const int64_t* target, float* loss_rows, void* dlogits, int ld_d,
                    int B, int C, float grad_scale, int dtype, int32_t* status, hipStream_t stream);
-/* (a target outside [0, C): that row's loss and gradient are NaN and, with status given,
- *  status[VQA_STATUS_BAD_TARGET] = 1; there is no ignore_index) */
+/* (a target outside [0, C): that row's loss is NaN, its gradient zero and, with status given,
+ *  status[VQA_STATUS_BAD_TARGET] = 1, which makes vqa_adam_step skip its update: CrossEntropyLoss raises for such a
+ *  target before optimizer.step(), train.py:201-204.  There is no ignore_index: -100 is out of range like any other
+ *  negative id; the reference's answer ids come from VocabEncoder and are never negative) */
 /* out[0] = scale * sum(x[0:n]) in a fixed order (mean reduction of the loss) */
 int vqa_sum_scale(const float* x, float* out, int n, float scale, hipStream_t stream);
 
@@ -368,10 +362,13 @@ int vqa_argmax_accuracy(const float* logits, int ld, int B, int C, const int64_t
                         int n_types, int64_t* pred, uint64_t* counters, hipStream_t stream);
 
 /* Adam on flat fp32 buffers (torch.optim.Adam defaults: no weight decay, no amsgrad);
- * grad is multiplied by grad_scale first; shadow_bf16 (optional) receives bf16(param).
+ * grad is multiplied by grad_scale first; shadow_bf16 (optional) receives bf16(param).  status (optional, the
+ * words vqa_softmax_ce writes): while status[VQA_STATUS_BAD_TARGET] is set the call changes nothing and
+ * status[VQA_STATUS_SKIPPED_STEP] keeps the `step` of the first call skipped.
  *                                                                   train.py:34, 204 */
 int vqa_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* shadow_bf16, long n,
-                  float lr, float beta1, float beta2, float eps, int step, float grad_scale, hipStream_t stream);
+                  float lr, float beta1, float beta2, float eps, int step, float grad_scale, int32_t* status,
+                  hipStream_t stream);
 
 #ifdef __cplusplus
 }

@@ -47,6 +47,21 @@ def main():
     torch.cuda.synchronize()
     assert float(t.sum()) == float(1 << 20)
     dist.destroy_process_group()
+    # the train driver as torch.distributed.run starts it (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* in the environment):
+    # it creates the RCCL group itself, trains one epoch with the collectives forced on, writes the checkpoints from
+    # rank 0 and tears the group down again
+    import tempfile
+    from vqa_amd import train as drv
+    os.environ.update({'RANK': '0', 'WORLD_SIZE': '1', 'LOCAL_RANK': '0', 'MASTER_ADDR': '127.0.0.1',
+                       'MASTER_PORT': str(int(port) + 1)})
+    with tempfile.TemporaryDirectory() as out:
+        hist = drv.main(['--model', 'VQAAttnModel', '--dataset', 'SYNTH', '--epochs', '2', '--bs', '16', '--lr', '0.001',
+                         '--synth-batches', '3', '--force-collectives', '--out', out],
+                        emb_size=40, question_out=64, visual_out=2048, attention_dim=48, fusion_in=64, fusion_hidden=32)
+        assert len(hist) == 2 and hist[1]['train_loss'] == hist[1]['train_loss']
+        assert sorted(os.listdir(out)) == ['ModelBestRSVQA_VQAAttnModel.pth', 'ModelRunningRSVQA_VQAAttnModel.pth',
+                                           'TrainState_VQAAttnModel.pth']
+    assert not dist.is_initialized()
     print('rccl single rank ok')
 
 

@@ -123,6 +123,60 @@ def test_out_of_range_ids_raise_at_the_next_sync():
         m2.sync()
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_bad_target_leaves_weights_and_moments_untouched(dtype):
+    """CrossEntropyLoss raises for a target outside [0, C) at the loss call, before backward() and optimizer.step()
+    (train.py:201-204): the reference's weights survive the bad batch.  Here the error surfaces only at the next
+    check, so the fused Adam kernel must skip every update from the bad step on (device-side status word); after
+    the IndexError the weights, the bf16 copies, both moments and the step counter are those of the last good step,
+    and training continues from there exactly like a run that never saw the bad batch.  -100 (torch's
+    ignore_index) is out of range like any other negative id."""
+    from vqa_amd.model import VQAAttnModel
+    kw = dict(vq=30, C=11, E=12, Hq=24, Dv=32, A=16, F=16, Hf=8)
+
+    def make():
+        return VQAAttnModel(['w'] * kw['vq'], ['a'] * kw['C'], None, dtype=dtype, emb_size=kw['E'], question_out=kw['Hq'],
+                            visual_out=kw['Dv'], attention_dim=kw['A'], fusion_in=kw['F'], fusion_hidden=kw['Hf'],
+                            seed=5).to('cuda').train()
+    b = vqa_ref.synthetic_batch(6, 9, kw['Dv'], 7, kw['vq'], kw['C'], seed=3)
+    f, t, a = b['feats'].cuda().to(dtype), b['tokens'].cuda(), b['answers'].cuda()
+    for bad_id in (kw['C'] + 5, -100):
+        m, ref = make(), make()
+        for mm in (m, ref):
+            mm.train_step(f, t, a, lr=1e-2)
+            mm.train_step(f, t, a, lr=1e-2)
+            mm.sync()
+        before = {k: v.clone() for k, v in m.state_dict().items()}
+        opt_before = m.optimizer_state_dict()
+        shadow_before = None if m._shadow is None else m._shadow.clone()
+        bad_a = a.clone()
+        bad_a[4] = bad_id
+        loss = m.train_step(f, t, bad_a, lr=1e-2).clone()     # (the returned tensor lives in the workspace)
+        m.train_step(f, t, a, lr=1e-2)            # a clean batch before the host has looked: skipped too
+        assert torch.isnan(loss).item()
+        with pytest.raises(IndexError, match='Target out of bounds'):
+            m.sync()
+        after = m.state_dict()
+        for k in before:
+            assert torch.isfinite(after[k]).all(), k
+            assert torch.equal(after[k], before[k]), k
+        opt_after = m.optimizer_state_dict()
+        assert opt_after['step_count'] == opt_before['step_count'] == 2
+        for k in opt_before['exp_avg']:
+            assert torch.equal(opt_after['exp_avg'][k], opt_before['exp_avg'][k]), k
+            assert torch.equal(opt_after['exp_avg_sq'][k], opt_before['exp_avg_sq'][k]), k
+        if shadow_before is not None:
+            assert torch.equal(m._shadow, shadow_before)
+        # the run goes on from the last good step: same weights as the run that never saw the bad batch
+        m.drop_step = ref.drop_step             # (the two skipped steps advanced the dropout stream)
+        m.train_step(f, t, a, lr=1e-2)
+        ref.train_step(f, t, a, lr=1e-2)
+        m.sync(); ref.sync()
+        sa, sb = m.state_dict(), ref.state_dict()
+        for k in sa:
+            assert torch.equal(sa[k], sb[k]), k
+
+
 @pytest.mark.parametrize('arch', ['lstm', '2-lstm'])
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_one_and_two_token_questions(arch, dtype):

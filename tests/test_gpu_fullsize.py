@@ -105,6 +105,30 @@ def test_cfg2_train_step_gradients_subbatch(full_model):
     assert 'attention.0.linear_va.weight' in checked and 'linear_classif2.weight' in checked
 
 
+def test_cfg2_full_batch_gradients_at_the_benched_shape(full_model):
+    """The exact shape bench.py times (B = 256, R = 196: the 256 x 256-tile projection over 50 176 rows and its
+    weight gradient over a 50 176-long contraction, split over K ranges and transposed back by the reduce) against
+    the oracle's autograd on the same 256 samples: logits, loss, and the gradients of the attention weights."""
+    m, p = full_model
+    m.eval()
+    b = vqa_ref.synthetic_batch(256, 196, 2048, 14, FULL['vq'], FULL['C'], seed=42)
+    feats = b['feats'].to(torch.bfloat16)
+    po = {k: v.to(torch.bfloat16).float() for k, v in p.items()}
+    logits_ref, loss_ref, grads = vqa_ref.loss_and_grads(po, feats.float(), b['tokens'], b['answers'], None, 1)
+    with torch.no_grad():
+        m._bptt = False
+        m._forward_impl(*m._prepare_inputs(feats.cuda(), b['tokens'].cuda(), None))
+        loss = m.loss_and_grad_logits(b['answers'].cuda())
+        m._backward_impl()
+    assert rel_err(m._ctx[0]['logits'][:, :3000], logits_ref) <= 1e-2
+    assert abs(float(loss) - float(loss_ref)) <= 1e-2 * float(loss_ref)
+    named = dict(m.named_parameters())
+    for k in ('attention.0.linear_va.weight', 'attention.0.linear_va.bias', 'attention.0.linear_qa.weight',
+              'attention.0.linear_a.weight', 'linear_v.weight', 'linear_classif2.weight'):
+        got = m._g(k).view(named[k].shape)
+        assert rel_err(got, grads[k]) <= 2e-2, (k, rel_err(got, grads[k]))
+
+
 def test_cfg4_caption_stream_gradients_full_width():
     """Config 4 at the real widths, forward AND backward on a batch of 8: masked mean + L2 of the caption embeddings,
     concatenation, the widened linear_classif1 (model.py:1571-1574, 1678, 1734-1741)."""

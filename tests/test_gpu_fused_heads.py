@@ -64,34 +64,3 @@ def test_fusion_from_both_slab_sets_matches_three_launches(dtype, B, F, pad, skv
          ptr(x_b), ldx, B, F, 31, 0.5, dt)
     torch.cuda.synchronize()
     assert torch.equal(xv_a, xv_b) and torch.equal(xq_a, xq_b) and torch.equal(x_a, x_b)
-
-
-@pytest.mark.parametrize('arch,Hq', [('lstm', 208), ('2-lstm', 416)])
-def test_fused_lstm_step_matches_the_two_launch_form(arch, Hq):
-    """vqa_lstm_step (recurrent product + cell update in one launch; off by default) against the split-K product
-    followed by the cell kernel: same question vectors up to the order of the fp32 sums, on ragged lengths including
-    an all-pad row, with and without the per-token table of input projections; and against the oracle."""
-    import torch
-    from oracle import vqa_ref
-    from vqa_amd.model import VQAAttnModel
-    kw = dict(vq=300, C=11, E=44, Hq=Hq, Dv=64, A=16, F=16, Hf=8)
-    p = vqa_ref.init_params(seed=3, two_lstm=(arch == '2-lstm'), **kw)
-    m = VQAAttnModel(['w'] * kw['vq'], ['a'] * kw['C'], None, dtype=torch.bfloat16, emb_size=kw['E'], question_out=Hq,
-                     visual_out=kw['Dv'], attention_dim=kw['A'], fusion_in=kw['F'], fusion_hidden=kw['Hf'], seed=1,
-                     seq2vec_arch=arch)
-    m.load_state_dict(p)
-    m = m.to('cuda').eval()
-    b = vqa_ref.synthetic_batch(150, 4, kw['Dv'], 14, kw['vq'], kw['C'], seed=8)
-    b['tokens'][3] = 0
-    tok = b['tokens'].cuda()
-    po = {k: v.to(torch.bfloat16).float() for k, v in p.items()}
-    ref = vqa_ref.encode_question(b['tokens'], po)
-    for fold in (True, False):
-        m.fold_embedding = m.fold_first_step = fold
-        m.fused_lstm_step = False
-        q_two = m.encode_question(tok).clone()
-        m.fused_lstm_step = True
-        q_one = m.encode_question(tok).clone()
-        assert float((q_one - q_two).abs().max()) <= 2e-2 * float(q_two.abs().max())     # bf16 h feeds back 13 times
-        assert float((q_one.cpu() - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
-    m.fused_lstm_step = False

@@ -46,6 +46,36 @@ def test_static_scratch_grid_mean_matches_workspace_form(dtype):
     assert nsplit == 1 and torch.equal(ref, got)
 
 
+def test_static_entry_point_allocates_nothing():
+    """Device memory in use (hipMemGetInfo through torch) is the same before and after calls of the static form:
+    the first call on the device (which looks the scratch address up) and a later one."""
+    from vqa_amd import _lib
+    from vqa_amd._lib import call, ptr
+    B, C, HW = 6, 512, 4096
+    x = torch.relu(torch.randn(B, HW, C)).to(torch.bfloat16).cuda()
+    out = torch.zeros(B, C, device='cuda')
+    _lib.load()
+    _lib.bind_stream()
+    # (the library's code object, static array included, is placed on the GPU when the process first uses the
+    #  library: run another of its entry points first so that this one-time load is not counted)
+    part = torch.empty(call('vqa_grid_mean_splits', 1, B, C, HW) * B * C, device='cuda')
+    call('vqa_grid_mean', ptr(x), 1, B, C, HW, ptr(out), C, 0, ptr(part), call('vqa_grid_mean_splits', 1, B, C, HW), _lib.BF16)
+    torch.cuda.synchronize()
+    for _ in range(2):
+        free0, _total = torch.cuda.mem_get_info()
+        call('vqa_grid_mean_static', ptr(x), 1, B, C, HW, ptr(out), C, 0, _lib.BF16)
+        torch.cuda.synchronize()
+        free1, _total = torch.cuda.mem_get_info()
+        assert free1 == free0, (free0, free1)
+    # a stream of torch's on the current device is accepted
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        _lib.bind_stream()
+        call('vqa_grid_mean_static', ptr(x), 1, B, C, HW, ptr(out), C, 0, _lib.BF16)
+    side.synchronize()
+    _lib.bind_stream()
+
+
 def test_static_scratch_limit_is_an_error():
     from vqa_amd import _lib
     from vqa_amd._lib import call, ptr

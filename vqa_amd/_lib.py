@@ -12,6 +12,8 @@ import os
 import torch
 
 F32, BF16 = 0, 1
+ABI_VERSION = 200          # VQA_HIP_VERSION of include/vqa_hip.h these signatures were written against
+STATUS_WORDS = 3           # VQA_STATUS_BAD_TOKEN, VQA_STATUS_BAD_TARGET, VQA_STATUS_SKIPPED_STEP
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('VQA_HIP_LIB', os.path.join(_HERE, 'libvqa_hip.so'))   # (override: A/B of kernel builds)
 
@@ -29,7 +31,6 @@ _SIGNATURES = {
     'vqa_lstm_cell_packed': [_p, _i, _z, _p, _i, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p, _p, _p, _u, _f, _i, _p],
     'vqa_lstm_cell_packed_table': [_p, _i, _z, _p, _i, _i, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p, _u, _f, _p, _i, _p],
     'vqa_lstm_cell01_table': [_p, _i, _p, _i, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p, _u, _f, _i, _p],
-    'vqa_lstm_step': [_p, _i, _p, _i, _p, _i, _i, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p, _u, _f, _i, _p],
     'vqa_lstm_cell_bwd_packed': [_p, _i, _z, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     'vqa_embedding_grad': [_p, _i, _z, _i, _p, _p, _p, _i, _p, _i, _i, _i, _p],
     'vqa_colsum_multi': [_p, _i, _p],
@@ -72,7 +73,7 @@ _SIGNATURES = {
     'vqa_softmax_ce': [_p, _i, _p, _p, _p, _i, _i, _i, _f, _i, _p, _p],
     'vqa_sum_scale': [_p, _p, _i, _f, _p],
     'vqa_argmax_accuracy': [_p, _i, _i, _i, _p, _p, _i, _p, _p, _p],
-    'vqa_adam_step': [_p, _p, _p, _p, _p, _l, _f, _f, _f, _f, _i, _f, _p],
+    'vqa_adam_step': [_p, _p, _p, _p, _p, _l, _f, _f, _f, _f, _i, _f, _p, _p],
 }
 _RESTYPE = {'vqa_last_error_string': C.c_char_p, 'vqa_attn_lds_bytes': C.c_size_t}
 _NO_STATUS = {'vqa_version', 'vqa_last_error_string', 'vqa_attn_lds_bytes', 'vqa_gemm_splitk_hint',
@@ -100,6 +101,9 @@ def load() -> C.CDLL:
             fn = getattr(lib, name)
             fn.argtypes = args
             fn.restype = _RESTYPE.get(name, C.c_int)
+        if lib.vqa_version() != ABI_VERSION:
+            raise VqaHipError(f'{LIB_PATH} is ABI version {lib.vqa_version()}, this binding needs {ABI_VERSION}: '
+                              'rebuild the library with `make`')
         _lib = lib
     return _lib
 

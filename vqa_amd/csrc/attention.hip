@@ -11,6 +11,7 @@
 // (recomputing tanh) and writes dP once.
 #include "common.h"
 #include "vqa_hip.h"
+#include <atomic>
 
 #define ATT_THREADS 1024
 #define ATT_WAVES (ATT_THREADS / 64)
@@ -814,6 +815,23 @@ k_attn_bwd_pipe(const bf16_t* __restrict__ P, int ldP, const bf16_t* __restrict_
     }
 }
 
+// Dynamic LDS beyond 48 KiB has to be granted per kernel: done once per kernel instance and device (to the whole
+// 160 KiB of a CU), not on every launch.
+template <auto Kernel>
+static int attn_reserve_lds(const char* what) {
+    static std::atomic<unsigned long long> done{0};          // one bit per device, one word per kernel instance
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return vqa_set_error(-22, what);
+    if (dev >= 0 && dev < 64 && ((done.load(std::memory_order_acquire) >> dev) & 1ull)) return 0;
+    hipFuncAttributes fa;                                     // (the kernel's static LDS counts against the same 160 KiB)
+    if (hipFuncGetAttributes(&fa, (const void*)Kernel) != hipSuccess) return vqa_set_error(-22, what);
+    const int room = 160 * 1024 - (int)fa.sharedSizeBytes;
+    if (hipFuncSetAttribute((const void*)Kernel, hipFuncAttributeMaxDynamicSharedMemorySize, room) != hipSuccess)
+        return vqa_set_error(-22, what);
+    if (dev >= 0 && dev < 64) done.fetch_or(1ull << dev, std::memory_order_release);
+    return 0;
+}
+
 extern "C" {
 
 size_t vqa_attn_lds_bytes(int R, int A, int Dv) {
@@ -860,7 +878,7 @@ static int attn_fwd_impl(const void* P, int ldP, const void* V, int ldV, const f
 #define ATT_FWD_ONLINE(NVA)                                                                                        \
   {                                                                                                                \
     if (lds_o > 48 * 1024)                                                                                         \
-        VQA_REQUIRE(hipFuncSetAttribute((const void*)k_attn_fwd_online<NVA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_o) == hipSuccess, "vqa_attn_fwd: cannot reserve LDS"); \
+        if (int rc = attn_reserve_lds<k_attn_fwd_online<NVA>>("vqa_attn_fwd: cannot reserve LDS")) return rc;      \
     k_attn_fwd_online<NVA><<<B, ATT_THREADS, lds_o, stream>>>((const bf16_t*)P, ldP, (const bf16_t*)V, ldV, qa, \
         ld_qa, w_a, c_a, inv_norm, p_out, (bf16_t*)pooled_t, pooled_f32, ld_pool, R, A, Dv, (bf16_t*)pooled_drop, drop_seed, thr, dsc, \
         q_slabs, q_nslab, q_stride, q_bias, const_cast<float*>(qa)); \
@@ -874,7 +892,7 @@ static int attn_fwd_impl(const void* P, int ldP, const void* V, int ldV, const f
 #define ATT_FWD_PIPE(NVA)                                                                                          \
   {                                                                                                                \
     if (lds_p > 48 * 1024)                                                                                         \
-        VQA_REQUIRE(hipFuncSetAttribute((const void*)k_attn_fwd_pipe<NVA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p) == hipSuccess, "vqa_attn_fwd: cannot reserve LDS"); \
+        if (int rc = attn_reserve_lds<k_attn_fwd_pipe<NVA>>("vqa_attn_fwd: cannot reserve LDS")) return rc;        \
     k_attn_fwd_pipe<NVA><<<B, ATT_THREADS, lds_p, stream>>>((const bf16_t*)P, ldP, (const bf16_t*)V, ldV, qa, \
         ld_qa, w_a, c_a, inv_norm, p_out, (bf16_t*)pooled_t, pooled_f32, ld_pool, R, A, Dv, (bf16_t*)pooled_drop, drop_seed, thr, dsc); \
   }
@@ -883,11 +901,11 @@ static int attn_fwd_impl(const void* P, int ldP, const void* V, int ldV, const f
         return vqa_check_launch("vqa_attn_fwd");
     }
     if (dtype == VQA_F32) {
-        VQA_REQUIRE(hipFuncSetAttribute((const void*)k_attn_fwd<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess, "vqa_attn_fwd: cannot reserve LDS");
+        if (int rc = attn_reserve_lds<k_attn_fwd<float>>("vqa_attn_fwd: cannot reserve LDS")) return rc;
         k_attn_fwd<float><<<B, ATT_THREADS, lds, stream>>>((const float*)P, ldP, (const float*)V, ldV, qa, ld_qa, w_a, c_a,
                                                           inv_norm, p_out, (float*)pooled_t, pooled_f32, ld_pool, R, A, Dv, (float*)pooled_drop, drop_seed, thr, dsc);
     } else if (dtype == VQA_BF16) {
-        VQA_REQUIRE(hipFuncSetAttribute((const void*)k_attn_fwd<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess, "vqa_attn_fwd: cannot reserve LDS");
+        if (int rc = attn_reserve_lds<k_attn_fwd<bf16_t>>("vqa_attn_fwd: cannot reserve LDS")) return rc;
         k_attn_fwd<bf16_t><<<B, ATT_THREADS, lds, stream>>>((const bf16_t*)P, ldP, (const bf16_t*)V, ldV, qa, ld_qa, w_a, c_a,
                                                            inv_norm, p_out, (bf16_t*)pooled_t, pooled_f32, ld_pool, R, A, Dv, (bf16_t*)pooled_drop, drop_seed, thr, dsc);
     } else return vqa_set_error(-22, "vqa_attn_fwd: dtype");
@@ -939,7 +957,7 @@ static int attn_bwd_impl(const void* P, int ldP, const void* V, int ldV, const f
 #define ATT_BWD_PIPE_(NVD, NTS)                                                                                    \
   {                                                                                                                \
     if (lds > 48 * 1024)                                                                                           \
-        VQA_REQUIRE(hipFuncSetAttribute((const void*)k_attn_bwd_pipe<NVD, NTS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess, "vqa_attn_bwd: cannot reserve LDS"); \
+        if (int rc = attn_reserve_lds<k_attn_bwd_pipe<NVD, NTS>>("vqa_attn_bwd: cannot reserve LDS")) return rc;   \
     k_attn_bwd_pipe<NVD, NTS><<<B, ATT_THREADS, lds, stream>>>((const bf16_t*)P, ldP, (const bf16_t*)V, ldV, qa, ld_qa, w_a,  \
         inv_norm, p_in, d_pooled, ld_dpool, (bf16_t*)dP, ld_dP, dqa_f32, (bf16_t*)dqa_t, ld_dqa, dwa_part, dc_part, R, A, Dv, \
         d_slabs, d_nslab, d_stride, d_seed, d_thr, d_scale); \
@@ -953,12 +971,12 @@ static int attn_bwd_impl(const void* P, int ldP, const void* V, int ldV, const f
         return vqa_check_launch("vqa_attn_bwd");
     }
     if (dtype == VQA_F32) {
-        VQA_REQUIRE(hipFuncSetAttribute((const void*)k_attn_bwd<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess, "vqa_attn_bwd: cannot reserve LDS");
+        if (int rc = attn_reserve_lds<k_attn_bwd<float>>("vqa_attn_bwd: cannot reserve LDS")) return rc;
         k_attn_bwd<float><<<B, ATT_THREADS, lds, stream>>>((const float*)P, ldP, (const float*)V, ldV, qa, ld_qa, w_a, inv_norm,
                                                           p_in, d_pooled, ld_dpool, (float*)dP, ld_dP, dqa_f32, (float*)dqa_t,
                                                           ld_dqa, dwa_part, dc_part, R, A, Dv);
     } else if (dtype == VQA_BF16) {
-        VQA_REQUIRE(hipFuncSetAttribute((const void*)k_attn_bwd<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess, "vqa_attn_bwd: cannot reserve LDS");
+        if (int rc = attn_reserve_lds<k_attn_bwd<bf16_t>>("vqa_attn_bwd: cannot reserve LDS")) return rc;
         k_attn_bwd<bf16_t><<<B, ATT_THREADS, lds, stream>>>((const bf16_t*)P, ldP, (const bf16_t*)V, ldV, qa, ld_qa, w_a, inv_norm,
                                                            p_in, d_pooled, ld_dpool, (bf16_t*)dP, ld_dP, dqa_f32, (bf16_t*)dqa_t,
                                                            ld_dqa, dwa_part, dc_part, R, A, Dv);

@@ -735,25 +735,26 @@ __global__ void __launch_bounds__(256) k_softmax_ce(const float* __restrict__ lo
     }
     se = block_sum(se, red);
     const int64_t y = target[b];
-    // a target outside [0, C) (torch.nn.CrossEntropyLoss raises for it): the row's loss and gradient are NaN, so the
-    // mistake cannot train silently, and the status word tells the host what happened
+    // a target outside [0, C) (torch.nn.CrossEntropyLoss raises for it before anything is updated): the row's loss is
+    // NaN, its gradient zero (a NaN would travel to every rank of a data-parallel group through the all-reduce), and
+    // the status word makes the Adam kernel leave the weights alone and tells the host what happened
     const bool bad = y < 0 || y >= C;
     if (threadIdx.x == 0) {
         loss_row[b] = bad ? __builtin_nanf("") : (logf(se) - (z[y] - mx));
         if (bad && status) status[VQA_STATUS_BAD_TARGET] = 1;
     }
     if (dlogits) {
-        const float inv = bad ? __builtin_nanf("") : 1.0f / se;
+        const float inv = 1.0f / se;
         if (keep) {
 #pragma unroll
             for (int k = 0; k < KEEP; ++k) {
                 const int c = threadIdx.x + 256 * k;
-                if (c < ld_d) dlogits[(size_t)b * ld_d + c] = from_f32<T>(c < C ? (zr[k] * inv - (c == y ? 1.f : 0.f)) * scale : 0.f);
+                if (c < ld_d) dlogits[(size_t)b * ld_d + c] = from_f32<T>((c < C && !bad) ? (zr[k] * inv - (c == y ? 1.f : 0.f)) * scale : 0.f);
             }
         } else {
             for (int c = threadIdx.x; c < ld_d; c += blockDim.x) {
                 float g = 0.f;
-                if (c < C) g = (expf(z[c] - mx) * inv - (c == y ? 1.f : 0.f)) * scale;
+                if (c < C && !bad) g = (expf(z[c] - mx) * inv - (c == y ? 1.f : 0.f)) * scale;
                 dlogits[(size_t)b * ld_d + c] = from_f32<T>(g);
             }
         }
@@ -819,7 +820,14 @@ __global__ void __launch_bounds__(256) k_argmax_accuracy(const float* __restrict
 __global__ void __launch_bounds__(256) k_adam(float* __restrict__ p, const float* __restrict__ g,
                                               float* __restrict__ m, float* __restrict__ v,
                                               bf16_t* __restrict__ shadow, long n, float lr, float b1, float b2,
-                                              float eps, float inv_bc1, float inv_sqrt_bc2, float grad_scale) {
+                                              float eps, float inv_bc1, float inv_sqrt_bc2, float grad_scale,
+                                              int* __restrict__ status, int step) {
+    // the loss kernel met a target the reference's CrossEntropyLoss raises for (train.py:201, before optimizer.step()):
+    // nothing is updated, and the first step skipped this way is recorded for the host
+    if (status && status[VQA_STATUS_BAD_TARGET] != 0) {
+        if (blockIdx.x == 0 && threadIdx.x == 0 && status[VQA_STATUS_SKIPPED_STEP] == 0) status[VQA_STATUS_SKIPPED_STEP] = step;
+        return;
+    }
     const long n4 = n >> 2;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         // gradients and moments are touched once per step: streamed past the caches; the parameters and
@@ -1359,7 +1367,8 @@ int vqa_argmax_accuracy(const float* logits, int ld, int B, int C, const int64_t
 }
 
 int vqa_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* shadow_bf16, long n,
-                  float lr, float beta1, float beta2, float eps, int step, float grad_scale, hipStream_t stream) {
+                  float lr, float beta1, float beta2, float eps, int step, float grad_scale, int32_t* status,
+                  hipStream_t stream) {
     VQA_REQUIRE(param && grad && exp_avg && exp_avg_sq && n >= 0 && step >= 1, "vqa_adam_step: bad arguments");
     VQA_REQUIRE((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0 &&
                 (((uintptr_t)shadow_bf16) & 7) == 0, "vqa_adam_step: buffers must be 16-byte aligned");
@@ -1368,7 +1377,7 @@ int vqa_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
     k_adam<<<grid_for((n + 3) / 4, 256), 256, 0, stream>>>(param, grad, exp_avg, exp_avg_sq, (bf16_t*)shadow_bf16, n, lr,
                                                            beta1, beta2, eps, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)),
-                                                           grad_scale);
+                                                           grad_scale, status, step);
     return vqa_check_launch("vqa_adam_step");
 }
 

@@ -24,6 +24,18 @@
 
 #include "gemm_tiles.h"
 
+// Development builds only (-DVQA_DEV): PP_PROBE = 1..4 compiles timing probes of the eight-phase kernel that skip its
+// DMA, its MFMAs or its stores (wrong results by construction), and VQA_GEMM_NT / VQA_GEMM_PP in the environment
+// override the store policy / the 256 x 256 engine for A/B runs.  The library build has neither.
+#if defined(PP_PROBE) && !defined(VQA_DEV)
+#error "PP_PROBE builds compute wrong results on purpose: they need -DVQA_DEV and must not be shipped"
+#endif
+#if defined(VQA_DEV) && defined(PP_PROBE)
+#define PP_PROBE_IS(n) (PP_PROBE == (n))
+#else
+#define PP_PROBE_IS(n) 0
+#endif
+
 // ---- epilogue ------------------------------------------------------------------
 // v = act(row_scale[m] * acc + bias[n]) written as fp32 or bf16 at out + split * split_stride.
 // A split-K launch writes plain fp32 partial sums (one slab per split).
@@ -117,7 +129,7 @@ __device__ __forceinline__ void epilogue_store(char* lds, f32x4 (&acc)[MT][NT], 
                 const f32x4 a = *reinterpret_cast<const f32x4*>(wl + rl * LDW + c);
                 const f32x4 b = *reinterpret_cast<const f32x4*>(wl + rl * LDW + c + 4);
                 bf16_t* dst = out + (size_t)m * epi.ld + n;
-#if defined(PP_PROBE) && PP_PROBE == 4
+#if PP_PROBE_IS(4)
                 if (a[0] + b[3] != 123.456f) continue;      // probe build: staging without the global stores (timing only)
 #endif
                 if (vec_ok && n + 8 <= N) {
@@ -859,7 +871,7 @@ k_gemm_bf16_pp(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__
     // quarter q = 4 t + j goes to slot q % 10; J is the compile-time quarter kind
     auto issue = [&](int q, auto J) {
         if (q >= nq) return;
-#if defined(PP_PROBE) && PP_PROBE == 1
+#if PP_PROBE_IS(1)
         if (q >= 7) return;                                  // probe build: the K loop issues no DMA (timing only)
 #endif
         char* dst = lds + (q % NQ) * QB;
@@ -873,7 +885,7 @@ k_gemm_bf16_pp(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__
     using J0 = std::integral_constant<int, 0>; using J1 = std::integral_constant<int, 1>;
     using J2 = std::integral_constant<int, 2>; using J3 = std::integral_constant<int, 3>;
 
-#if defined(PP_PROBE) && PP_PROBE == 2
+#if PP_PROBE_IS(2)
     constexpr bool kCompute = false;                         // probe build: DMA and barriers only (timing only)
 #else
     constexpr bool kCompute = true;
@@ -978,7 +990,7 @@ k_gemm_bf16_pp(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__
     ss[0] = ssp[0][0] + ssp[0][1];
     ss[1] = ssp[1][0] + ssp[1][1];
     if (wm == 0) __builtin_amdgcn_s_barrier();              // the barrier waves 4-7 took at the start
-#if defined(PP_PROBE) && PP_PROBE == 3
+#if PP_PROBE_IS(3)
     {                                                        // probe build: no output stores (timing only)
         float s = 0.f;
         for (int i = 0; i < MT; ++i) for (int j = 0; j < NT; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
@@ -1062,16 +1074,31 @@ k_gemm_valu(const T* __restrict__ A, int lda, const T* __restrict__ B, int ldb, 
 // ---- host side ----------------------------------------------------------------------
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// The bf16 kernels a product can run on (workgroup tile + schedule)
+enum TileEngine {
+    TILE_64 = 0,          // 64 x 64, 4 waves, two-slot ring (k_gemm_bf16)
+    TILE_128,             // 128 x 128, same kernel
+    TILE_256x128,         // 256 x 128, 8 waves, three-slot ring (k_gemm_bf16_w8<128>)
+    TILE_256_W8,          // 256 x 256, 8 waves, two-slot ring (k_gemm_bf16_w8<256>)
+    TILE_256_R10,         // 256 x 256, ring of ten quarter-operand slots (k_gemm_bf16_r10<PF = 0>)
+    TILE_256_R10PF,       // same, all fragments of a K tile read before its MFMAs (k_gemm_bf16_r10<PF = 1>)
+    TILE_256_PP           // 256 x 256, eight-phase schedule with staggered wave groups (k_gemm_bf16_pp)
+};
+static inline bool tile_is_256sq(int t) { return t >= TILE_256_W8; }
+static inline int tile_rows(int t) { return t == TILE_64 ? 64 : t == TILE_128 ? 128 : 256; }
+static inline int tile_cols(int t) { return t == TILE_64 ? 64 : (t == TILE_128 || t == TILE_256x128) ? 128 : 256; }
+
 // tile choice shared by the launcher and the split-K hint: 128x128 workgroup tiles when the
-// output has enough of them, 64x64 otherwise; engine 2 / 3 force 64 / 128
+// output has enough of them, 64x64 otherwise; the `engine` argument of the entry points forces one:
+// 2 / 3 / 4 / 6 / 8 / 9 / 10 in the order of TileEngine (0 = choose, 1 = the VALU kernel)
 static inline int pick_tile(int M, int N, int K, int akm, int bkm, int engine) {
-    if (engine == 2) return 64;
-    if (engine == 3) return 128;
-    if (engine == 4) return 256;
-    if (engine == 6) return 512;                          // 256 x 256 tiles
-    if (engine == 8) return 2048;                         // 256 x 256 tiles, ten-quarter ring
-    if (engine == 9) return 4096;                         // same, all fragments of a K tile read before its MFMAs
-    if (engine == 10) return 8192;                        // 256 x 256 tiles, eight-phase schedule with staggered wave groups
+    if (engine == 2) return TILE_64;
+    if (engine == 3) return TILE_128;
+    if (engine == 4) return TILE_256x128;
+    if (engine == 6) return TILE_256_W8;
+    if (engine == 8) return TILE_256_R10;
+    if (engine == 9) return TILE_256_R10PF;
+    if (engine == 10) return TILE_256_PP;
     const long t128 = (long)ceil_div(M, 128) * ceil_div(N, 128);
     const long t256 = (long)ceil_div(M, 256) * ceil_div(N, 128);
     const long t512 = (long)ceil_div(M, 256) * ceil_div(N, 256);
@@ -1085,18 +1112,21 @@ static inline int pick_tile(int M, int N, int K, int akm, int bkm, int engine) {
     const bool ragged = akm && bkm && b512 < 1024 && b512 * 4 < r512 * 3 && t256 * r512 > b512 * r256;
     // 256 x 256 tiles; with both operands k-major the ten-quarter ring variant that reads a whole K tile's fragments
     // before its MFMAs (engine 9) is the faster one: 6-8 % at 8192^3, 2 % on the image projection inside the step
-    if (M >= 384 && N >= 192 && t512 >= 32 && t512 * split512 >= 192 && !ragged) return (akm && bkm) ? 4096 : 512;
-    if (akm && bkm && M >= 192 && N > 64 && t256 >= 40) return 256;   // 256 x 128 tiles, 3-stage ring
+    if (M >= 384 && N >= 192 && t512 >= 32 && t512 * split512 >= 192 && !ragged) return (akm && bkm) ? TILE_256_R10PF : TILE_256_W8;
+    if (akm && bkm && M >= 192 && N > 64 && t256 >= 40) return TILE_256x128;
     // a short contraction (a handful of K steps) is all ramp-up: more, smaller workgroups start and finish
     // sooner unless the 128 x 128 tiles already give every CU one
-    if (K <= 512 && t128 < 256) return 64;
-    return (M > 64 && N > 64 && t128 >= 40) ? 128 : 64;
+    if (K <= 512 && t128 < 256) return TILE_64;
+    return (M > 64 && N > 64 && t128 >= 40) ? TILE_128 : TILE_64;
 }
 
-// Streaming (non-temporal) output stores pay when the output is large and every row starts on a 128-byte line;
-// VQA_GEMM_NT=0 / 1 in the environment forces them off / on (A/B runs).
+// Streaming (non-temporal) output stores pay when the output is large and every row starts on a 128-byte line.
 static inline int want_nt_store(const Epi& epi, int M, int N, int splitk) {
+#ifdef VQA_DEV
     static const int forced = [] { const char* e = getenv("VQA_GEMM_NT"); return e ? atoi(e) : -1; }();
+#else
+    constexpr int forced = -1;
+#endif
     const size_t esz = epi.out_bf16 ? 2 : 4;
     const bool aligned = (((size_t)epi.ld * esz) % 128 == 0) && (((uintptr_t)epi.out) % 128 == 0) && ((epi.split_stride * 4) % 128 == 0);
     if (!aligned) return 0;
@@ -1104,10 +1134,14 @@ static inline int want_nt_store(const Epi& epi, int M, int N, int splitk) {
     return (size_t)M * N * esz * splitk >= ((size_t)96 << 20);
 }
 
-// VQA_GEMM_PP=0 in the environment keeps the ring kernels as the default 256 x 256 engine (A/B runs)
+// The eight-phase kernel is the default 256 x 256 engine (development builds: VQA_GEMM_PP=0 keeps the ring kernels)
 static inline bool use_eight_phase() {
+#ifdef VQA_DEV
     static const bool on = [] { const char* e = getenv("VQA_GEMM_PP"); return !e || atoi(e) != 0; }();
     return on;
+#else
+    return true;
+#endif
 }
 
 static int launch_bf16(const void* A, int lda, int akm, const void* B, int ldb, int bkm, int M, int N, int K,
@@ -1117,14 +1151,15 @@ static int launch_bf16(const void* A, int lda, int akm, const void* B, int ldb, 
     // when there are many row tiles (a packed batch of sequences), for all of them otherwise
     const int m_sched = (epi.m_limit && M >= 1024) ? M / 2 : M;
     int bm = pick_tile(m_sched, N, K, akm, bkm, engine);
-    if (engine == 0 && (bm == 4096 || bm == 512) && use_eight_phase()) bm = 8192;   // (falls back below when the shape does not fit)
-    const bool big = bm == 128;
-    const int bmr = bm >= 256 ? 256 : bm, bnr = bm >= 512 ? 256 : (bm == 256 ? 128 : bm);
-    const int tm = ceil_div(M, bmr), tn = ceil_div(N, bnr);
+    if (engine == 0 && (bm == TILE_256_R10PF || bm == TILE_256_W8) && use_eight_phase()) bm = TILE_256_PP;   // (falls back below when the shape does not fit)
+    const bool big = bm == TILE_128;
+    const int tm = ceil_div(M, tile_rows(bm)), tn = ceil_div(N, tile_cols(bm));
     const unsigned grid = (unsigned)(tm * tn * splitk);
     const bf16_t* a = (const bf16_t*)A; const bf16_t* b = (const bf16_t*)B;
-    if (bm == 8192 && (kps % GEMM_BK || K % GEMM_BK || epi.m_limit || epi.k_limit || (epi.out_bf16 && !bkm))) return launch_bf16(A, lda, akm, B, ldb, bkm, M, N, K, splitk, (akm && bkm) ? 9 : 6, epi, stream);
-    if (bm == 8192) {
+    // the eight-phase kernel takes whole K tiles, no device-side limits, and bf16 output only with a k-major B
+    if (bm == TILE_256_PP && (kps % GEMM_BK || K % GEMM_BK || epi.m_limit || epi.k_limit || (epi.out_bf16 && !bkm)))
+        return launch_bf16(A, lda, akm, B, ldb, bkm, M, N, K, splitk, (akm && bkm) ? 9 : 6, epi, stream);
+    if (bm == TILE_256_PP) {
         const bool nts = want_nt_store(epi, M, N, splitk);
 #define LAUNCHP(AK, BK_)                                                                                              \
     do { if (nts) k_gemm_bf16_pp<AK, BK_, false, true><<<grid, 512, 0, stream>>>(a, lda, b, ldb, M, N, K, tm, tn, kps, epi); \
@@ -1136,9 +1171,9 @@ static int launch_bf16(const void* A, int lda, int akm, const void* B, int ldb, 
 #undef LAUNCHP
         return 0;
     }
-    if (bm == 2048 || bm == 4096) {
+    if (bm == TILE_256_R10 || bm == TILE_256_R10PF) {
 #define LAUNCHR(AK, BK_)                                                                                              \
-    do { if (bm == 2048) k_gemm_bf16_r10<AK, BK_, 0><<<grid, 512, 0, stream>>>(a, lda, b, ldb, M, N, K, tm, tn, kps, epi); \
+    do { if (bm == TILE_256_R10) k_gemm_bf16_r10<AK, BK_, 0><<<grid, 512, 0, stream>>>(a, lda, b, ldb, M, N, K, tm, tn, kps, epi); \
          else k_gemm_bf16_r10<AK, BK_, 1><<<grid, 512, 0, stream>>>(a, lda, b, ldb, M, N, K, tm, tn, kps, epi); } while (0)
         if (akm && bkm) LAUNCHR(true, true);
         else if (akm && !bkm) LAUNCHR(true, false);
@@ -1147,9 +1182,9 @@ static int launch_bf16(const void* A, int lda, int akm, const void* B, int ldb, 
 #undef LAUNCHR
         return 0;
     }
-    if (bm >= 256) {
+    if (bm == TILE_256x128 || bm == TILE_256_W8) {
 #define LAUNCH8(AK, BK_)                                                                                             \
-    do { if (bm == 256) k_gemm_bf16_w8<AK, BK_, 128><<<grid, 512, 0, stream>>>(a, lda, b, ldb, M, N, K, tm, tn, kps, epi); \
+    do { if (bm == TILE_256x128) k_gemm_bf16_w8<AK, BK_, 128><<<grid, 512, 0, stream>>>(a, lda, b, ldb, M, N, K, tm, tn, kps, epi); \
          else k_gemm_bf16_w8<AK, BK_, 256><<<grid, 512, 0, stream>>>(a, lda, b, ldb, M, N, K, tm, tn, kps, epi); } while (0)
         if (akm && bkm) LAUNCH8(true, true);
         else if (akm && !bkm) LAUNCH8(true, false);
@@ -1211,8 +1246,8 @@ extern "C" {
 // keeping at least 4 (128-tile) / 4 (64-tile) K steps of 64 per split
 int vqa_gemm_splitk_hint(int M, int N, int K, int a_kmajor, int b_kmajor) {
     const int bm = pick_tile(M, N, K, a_kmajor, b_kmajor, 0);
-    const long tiles = (long)ceil_div(M, bm >= 256 ? 256 : bm) * ceil_div(N, bm >= 512 ? 256 : (bm == 256 ? 128 : bm));
-    int s = (int)((bm >= 256 ? 256 : 512) / tiles);   // one round of workgroups: 1 per CU (256 tiles) or 2 per CU
+    const long tiles = (long)ceil_div(M, tile_rows(bm)) * ceil_div(N, tile_cols(bm));
+    int s = (int)((tile_rows(bm) == 256 ? 256 : 512) / tiles);   // one round of workgroups: 1 per CU (256-row tiles) or 2 per CU
     const int maxs = K / 256 > 0 ? K / 256 : 1;
     if (s > maxs) s = maxs;
     if (s > 32) s = 32;
@@ -1322,8 +1357,8 @@ int vqa_gemm_fused_rownorm(const void* A, int lda, const void* B, int ldb, void*
     VQA_REQUIRE(C && ldc >= N && inv_norm, "vqa_gemm_fused_rownorm: bad output");
     VQA_REQUIRE(act == 0 || act == 1, "vqa_gemm_fused_rownorm: act must be 0 (none) or 1 (tanh)");
     VQA_REQUIRE(out_dtype == VQA_F32 || out_dtype == VQA_BF16, "vqa_gemm_fused_rownorm: out_dtype");
-    const int bm = (dtype == VQA_BF16 && engine != 1) ? pick_tile(M, N, K, 1, 1, engine) : 0;
-    if (bm == 2048 || bm == 4096 || bm == 8192) {
+    const int bm = (dtype == VQA_BF16 && engine != 1) ? pick_tile(M, N, K, 1, 1, engine) : TILE_64;
+    if (bm == TILE_256_R10 || bm == TILE_256_R10PF || bm == TILE_256_PP) {
         Epi epi{C, ldc, out_dtype == VQA_BF16, 0, bias, nullptr, act, nullptr, nullptr, inv_norm};
         const int tm = ceil_div(M, 256), tn = ceil_div(N, 256);
         const int kps = ceil_div(K, GEMM_BK) * GEMM_BK;

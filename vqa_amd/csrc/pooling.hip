@@ -305,6 +305,15 @@ int vqa_grid_mean_static(const void* x, int layout, int B, int C, int HW, float*
         hipError_t e = hipGetDevice(&dev);
         if (e != hipSuccess || dev < 0 || dev >= kMaxDevices)
             return vqa_set_error(-1000 - (int)e, "vqa_grid_mean_static: hipGetDevice failed or device index >= 64");
+        // the scratch used is the CURRENT device's copy, and the kernels run on the device that owns `stream`: the
+        // two must be the same GPU (the null stream belongs to the current device)
+        if (stream) {
+            hipDevice_t sdev = -1;
+            e = hipStreamGetDevice(stream, &sdev);
+            if (e != hipSuccess || (int)sdev != dev)
+                return vqa_set_error(-22, "vqa_grid_mean_static: `stream` does not belong to the current device "
+                                          "(make the stream's GPU current before the call)");
+        }
         {
             std::lock_guard<std::mutex> lock(g_static_scratch_mutex);
             if (!g_static_scratch_ptr[dev]) {

@@ -490,13 +490,18 @@ class _VQAHeadModel(nn.Module):
             for dy, ld_dy, x, ldx, wname, M, N, K in items:
                 self._wgrad(dy, ld_dy, x, ldx, wname, M, N, K, defer=True)
             return
-        problems = []
-        for dy, ld_dy, x, ldx, wname, M, N, K in items:
-            sk = call('vqa_gemm_splitk_hint', M, N, K, 0, 0)
+        # the group's whole arena need is reserved in one piece: a flush in the middle of the list (the arena
+        # running full) would reduce partial sums of products that have not been launched yet
+        sks = [call('vqa_gemm_splitk_hint', M, N, K, 0, 0) for *_, M, N, K in items]
+        need = sum((sk * M * N + 63) // 64 * 64 for sk, (*_, M, N, K) in zip(sks, items) if sk > 1)
+        base = self._arena(need, items[0][0].device) if need else 0
+        problems, off = [], 0
+        for sk, (dy, ld_dy, x, ldx, wname, M, N, K) in zip(sks, items):
             if sk == 1:
                 addr = ptr(self._g(wname))
             else:
-                addr = self._arena(sk * M * N, dy.device)
+                addr = base + 4 * off
+                off += (sk * M * N + 63) // 64 * 64
                 self._wgrad_pending.append((addr, sk, M * N, M * N, self._g(wname)))
             problems.append((ptr(dy), ld_dy, ptr(x), ldx, addr, M * N, N, M, N, K, sk))
         _lib.gemm_slabs_group(problems, 0, 0, self.dt, colsums)       # (bias gradients ride in the same launch)
@@ -660,20 +665,9 @@ class _VQAHeadModel(nn.Module):
                      ptr(q_drop[0]) if fuse_drop else None, q_drop[1] if fuse_drop else 0,
                      q_drop[2] if fuse_drop else 0.0, dt)
                 t_first = 2
-            # steps with a recurrent product: one launch each (product + cell, vqa_lstm_step) when nothing has to be
-            # saved for backward through time; h ping-pongs between two buffers (the step reads all of h_{t-1})
-            fused = self.fused_lstm_step and dt == _lib.BF16 and Hh % 16 == 0 and not save
-            h_cur, h_alt = ws['h'], ws['h2']
+            h_cur = ws['h']
             for t in range(t_first, L):
                 hh_tab = self._hh_table if (from_table and t == 1) else None     # step 1's recurrent product, tabulated
-                if fused and t > 0 and hh_tab is None:
-                    call('vqa_lstm_step', ptr(h_cur), Hh, ptr(whh), Hh, ptr(table if from_table else ws['xg']), 4 * Hh,
-                         table.shape[0] if from_table else 0, ptr(tokens) if from_table else None, ptr(ws['c']),
-                         ptr(h_alt), Hh, ptr(ws['len']), q32, qT, Hq, B, Hh, t, L, ptr(ws['perm']), ptr(ws['m_t']),
-                         ptr(ws['offs']), ptr(hs), Hh, ptr(q_drop[0]) if fuse_drop else None,
-                         q_drop[1] if fuse_drop else 0, q_drop[2] if fuse_drop else 0.0, dt)
-                    h_cur, h_alt = h_alt, h_cur
-                    continue
                 if t == 0 or hh_tab is not None:
                     slab, sk, stride = None, 0, 0
                 else:
@@ -704,10 +698,6 @@ class _VQAHeadModel(nn.Module):
     # region projection holds every CU's LDS, so the encoder's kernels only run as its workgroups retire (-6 us per
     # step same-box, and the projection's own span grows by what the encoder takes)
     overlap_encoder = False
-    # recurrent product + cell update of a step in one launch (vqa_lstm_step; bf16, nothing saved for BPTT).  Off by
-    # default: every workgroup has to read all of h_{t-1}, twice the operand traffic of the split-K product, and the
-    # step got slower (+76 us per train step same-box at B = 256, Hq = 2400)
-    fused_lstm_step = False
 
     def _side_stream(self, device):
         st = getattr(self, '_side', None)
@@ -736,7 +726,7 @@ class _VQAHeadModel(nn.Module):
         Hh = max(rnn.hidden_size for rnn in self.seq2vec.layers)
         ws.update({'len': z((B,), torch.int32), 'perm': z((B,), torch.int32), 'm_t': z((L,), torch.int32),
                    'offs': z((L + 1,), torch.int32), 'x_emb': z((L * B, Ep), tdt), 'xg': z((L * B, 4 * Hh), tdt),
-                   'c': z((B, Hh), f32), 'h': z((B, Hh), tdt), 'h2': z((B, Hh), tdt), 'q32': z((B, H), f32), 'qT': z((B, H), tdt)})
+                   'c': z((B, Hh), f32), 'h': z((B, Hh), tdt), 'q32': z((B, H), f32), 'qT': z((B, H), tdt)})
         if len(self.seq2vec.layers) > 1:
             ws['hs'] = z((L * B, Hh), tdt)
         if self.train_encoder:                        # state kept for backward through time
@@ -971,7 +961,7 @@ class _VQAHeadModel(nn.Module):
         sh = None if self._shadow is None else self._shadow.data_ptr() + 2 * lo
         call('vqa_adam_step', self._flat.data_ptr() + 4 * lo, self._flat_grad.data_ptr() + 4 * lo,
              self._exp_avg.data_ptr() + 4 * lo, self._exp_avg_sq.data_ptr() + 4 * lo, sh, hi - lo, lr, betas[0], betas[1],
-             eps, step, grad_scale)
+             eps, step, grad_scale, ptr(self._status_words(self._flat.device)))
 
     def adam_step(self, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, grad_scale: float = 1.0):
         """One fused Adam update of every trainable parameter from the flat gradient buffer."""
@@ -1002,21 +992,26 @@ class _VQAHeadModel(nn.Module):
     def _status_words(self, device) -> torch.Tensor:
         st = getattr(self, '_status', None)
         if st is None or st.device != device:
-            self._status = st = torch.zeros(2, dtype=torch.int32, device=device)
+            self._status = st = torch.zeros(_lib.STATUS_WORDS, dtype=torch.int32, device=device)
         return st
 
     def check_status(self) -> None:
         """Read the device-side status words (one small copy, which synchronises with the stream) and raise what the
         reference's stock modules would have raised at the offending call: IndexError for a question token outside
         the embedding table (nn.Embedding, seq2vec.py:42) or an answer id outside [0, C) (CrossEntropyLoss,
-        train.py:201).  The kernels do not stop: a bad token reads the pad row, a bad target makes its row's loss and
-        gradient NaN.  Called by sync(), state_dict() and the train / evaluation drivers."""
+        train.py:201).  The kernels do not stop: a bad token reads the pad row; a bad target makes its row's loss NaN
+        and, as the reference raises before optimizer.step() (train.py:201-204), the fused Adam kernel leaves weights
+        and moments untouched from that step on until this check has raised (the optimiser step counter is rewound to
+        the last update that was applied).  ignore_index is not implemented: -100 is out of range like any negative
+        id.  Called by sync(), state_dict() and the train / evaluation drivers."""
         st = getattr(self, '_status', None)
         if st is None:
             return
-        tok, tgt = st.tolist()
+        tok, tgt, skipped = st.tolist()
         if tok or tgt:
             st.zero_()
+            if skipped:
+                self.step_count = skipped - 1
             what = []
             if tok:
                 what.append(f'a question token id outside [0, {self.seq2vec.embedding.num_embeddings})')
@@ -1061,6 +1056,16 @@ class _VQAHeadModel(nn.Module):
                 scale = reducer.finish() if reducer is not None else 1.0
                 self.adam_step(lr, betas, eps, grad_scale=scale)
         return loss
+
+    def eval_step(self, input_v, input_q, answers, captions=None) -> torch.Tensor:
+        """forward + mean cross-entropy with no gradient bookkeeping (the validation / test passes of train.py:96-97,
+        test.py:78-79).  Returns the loss as a 1-element device tensor; the logits stay in the workspace for
+        predict()."""
+        feats, tokens, captions = self._prepare_inputs(input_v, input_q, captions)
+        with torch.no_grad():
+            self._bptt = False
+            self._forward_impl(feats, tokens, captions)
+            return self.loss_and_grad_logits(answers)
 
     def optimizer_state_dict(self) -> Dict[str, object]:
         """Adam moments per parameter name plus the step / dropout counters (the reference

@@ -1,6 +1,10 @@
 """Evaluation driver with the reference's command line (vqa_model/test.py:119-128):
 
     python -m vqa_amd.test --model VQAAttnModel --dataset SYNTH --bs 256 --gpu 0 [--models-dir DIR]
+    python -m vqa_amd.test --model VQAAttnModel --dataset LR --data-path ../data/lrdataset --features-dir FEATS
+
+``--dataset LR`` / ``HR`` evaluate the reference's test split (``*_split_test_*.json`` under ``--data-path``,
+test.py:136-151) through VocabEncoder + FeatureVQALoader + a DataLoader, as vqa_amd.train does for the other splits.
 
 As vqa_model/test.py:29-110, 172-205: build the model, load ``ModelBestRSVQA_<model>.pth`` from the model folder
 (``../data/dump-models/<dataset>`` upstream; ``--models-dir`` here), run one no-grad pass in eval mode over the test
@@ -16,7 +20,7 @@ import os
 import torch
 
 from .metrics import AccuracyMeter, HR_TYPES, LR_TYPES
-from .train import SynthVQADataset, evaluate, model_and_geometry
+from .train import SynthVQADataset, add_data_arguments, evaluate, model_and_geometry, real_data
 
 
 def test(model, test_dataset, args, Dataset='HR', out=print):
@@ -34,7 +38,7 @@ def test(model, test_dataset, args, Dataset='HR', out=print):
     return res
 
 
-def main(argv=None):
+def main(argv=None, **model_kw):
     parser = argparse.ArgumentParser(description='MI355X VQA evaluation')
     parser.add_argument('--bs', type=int, default=70)
     parser.add_argument('--gpu', type=int, default=0)
@@ -44,14 +48,19 @@ def main(argv=None):
     parser.add_argument('--models-dir', type=str, default=None,
                         help='folder holding ModelBestRSVQA_<model>.pth (reference: ../data/dump-models/<dataset>)')
     parser.add_argument('--batches', type=int, default=4, help='SYNTH: number of test batches')
+    add_data_arguments(parser)
     args = parser.parse_args(argv)
-    if args.dataset != 'SYNTH':
-        raise SystemExit('only --dataset SYNTH is available (LR / HR need image files and a feature extractor)')
+    if args.dataset not in ('SYNTH', 'LR', 'HR'):
+        raise SystemExit('--dataset must be SYNTH, LR or HR')
     dev = torch.device(f'cuda:{args.gpu}')
     torch.cuda.set_device(dev)
-    model, geo = model_and_geometry(args, dev)
-    test_ds = SynthVQADataset(args.batches, args.bs, geo['R'], geo['Dv'], geo['L'], geo['Vq'], geo['C'], dev, seed=44,
-                              stage_maps=geo['stage_maps'])
+    if args.dataset == 'SYNTH':
+        model, geo = model_and_geometry(args, dev, **model_kw)
+        test_ds = SynthVQADataset(args.batches, args.bs, geo['R'], geo['Dv'], geo['L'], geo['Vq'], geo['C'], dev, seed=44,
+                                  stage_maps=geo['stage_maps'])
+    else:
+        model, (test_ds,), _, _ = real_data(args, dev, ('test',), feature_dtype=model_kw.get('dtype', torch.bfloat16),
+                                            **model_kw)
     folder = args.models_dir or f'../data/dump-models/{args.dataset}'
     path = os.path.join(folder, f'ModelBestRSVQA_{args.model}.pth')
     model.load_state_dict(torch.load(path, map_location=dev, weights_only=True))
