@@ -36,7 +36,7 @@ def make(M, N, K, akm, bkm, dtype, seed):
 SHAPES = [(37, 50, 72), (130, 70, 200), (300, 129, 64), (257, 384, 1000), (512, 136, 40), (64, 64, 8), (1, 9, 640)]
 
 
-@pytest.mark.parametrize('engine', [2, 3, 4, 6, 8, 9, 10, 1])
+@pytest.mark.parametrize('engine', [2, 3, 4, 6, 8, 9, 10, 11, 1])
 @pytest.mark.parametrize('akm,bkm', [(1, 1), (1, 0), (0, 1), (0, 0)])
 def test_slab_gemm_all_layouts(engine, akm, bkm):
     for si, (M, N, K) in enumerate(SHAPES):
@@ -50,22 +50,23 @@ def test_slab_gemm_all_layouts(engine, akm, bkm):
             assert err <= 2e-5, (engine, akm, bkm, M, N, K, sk, err)
 
 
+@pytest.mark.parametrize('engine', [10, 11])
 @pytest.mark.parametrize('akm,bkm', [(1, 1), (1, 0), (0, 1), (0, 0)])
-def test_eight_phase_engine_whole_k_tiles(akm, bkm):
+def test_eight_phase_engine_whole_k_tiles(akm, bkm, engine):
     """The eight-phase 256 x 256 engine takes contractions made of whole 64-wide K tiles (others fall back to the
     ring engine): one K tile, two, an odd count, many; ragged M / N; split-K with an uneven last split."""
     for si, (M, N, K) in enumerate([(300, 129, 64), (515, 300, 128), (257, 520, 192), (100, 1200, 640), (1000, 264, 2048)]):
         for sk in (1, 3):
             As, lda, Bs, ldb, ref = make(M, N, K, akm, bkm, torch.bfloat16, 300 + 10 * si + sk)
             slab = torch.full((sk, M, N), float('nan'), device='cuda')
-            call('vqa_gemm_slabs', ptr(As), lda, akm, ptr(Bs), ldb, bkm, ptr(slab), M * N, N, M, N, K, sk, BF16, 10)
+            call('vqa_gemm_slabs', ptr(As), lda, akm, ptr(Bs), ldb, bkm, ptr(slab), M * N, N, M, N, K, sk, BF16, engine)
             torch.cuda.synchronize()
             got = slab.double().sum(0)
             err = float((got - ref).abs().max() / ref.abs().max())
-            assert err <= 2e-5, (akm, bkm, M, N, K, sk, err)
+            assert err <= 2e-5, (engine, akm, bkm, M, N, K, sk, err)
 
 
-@pytest.mark.parametrize('engine', [2, 3, 4, 6, 8, 9, 10])
+@pytest.mark.parametrize('engine', [2, 3, 4, 6, 8, 9, 10, 11])
 @pytest.mark.parametrize('out_dtype', [torch.bfloat16, torch.float32])
 def test_fused_epilogue(engine, out_dtype):
     for si, (M, N, K) in enumerate([(300, 136, 256), (515, 1200, 192), (96, 8, 72)]):
@@ -121,7 +122,8 @@ def test_device_side_row_limit(engine, akm, bkm):
 
 @pytest.mark.parametrize('M,N,K', [(12547, 1200, 2072), (300, 136, 256), (4099, 520, 64), (50176, 1200, 2048)])
 @pytest.mark.parametrize('out_dtype', [torch.bfloat16, torch.float32])
-def test_projection_with_fused_row_norm(M, N, K, out_dtype):
+@pytest.mark.parametrize('engine', [0, 10, 11])
+def test_projection_with_fused_row_norm(M, N, K, out_dtype, engine):
     """C = normalize(A) B^T + bias in one call (ring kernel: norms from the A tiles in LDS; small products: norm
     kernel + product), and the inverse norms it stores, against fp64 from the same bf16 operands."""
     As, lda, Bs, ldb, ref = make(M, N, K, 1, 1, torch.bfloat16, M % 97)
@@ -133,7 +135,7 @@ def test_projection_with_fused_row_norm(M, N, K, out_dtype):
     C = torch.zeros(M, ldc, device='cuda', dtype=out_dtype)
     inv = torch.full((M,), float('nan'), device='cuda')
     call('vqa_gemm_fused_rownorm', ptr(As), lda, ptr(Bs), ldb, ptr(C), ldc, M, N, K, ptr(bias), ptr(inv), 0,
-         BF16 if out_dtype == torch.bfloat16 else F32, BF16, 0)
+         BF16 if out_dtype == torch.bfloat16 else F32, BF16, engine)
     torch.cuda.synchronize()
     norm = As[:, :K].double().norm(dim=1)
     inv_ref = 1.0 / norm.clamp_min(1e-12)

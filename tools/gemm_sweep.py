@@ -26,13 +26,16 @@ def run_fused(name, M, N, K, engines, ldc=None):
         us = timeit(lambda: call('vqa_gemm_fused', ptr(A), K, 1, ptr(Bm), K, 1, ptr(C), ldc, M, N, K, ptr(bias), ptr(rs), 0, 1, 1, eng))
         print(f'{name:12s} fused bf16 out ldc={ldc} M={M:6d} N={N:5d} K={K:6d} engine={eng:2d}: {us:8.1f} us  {2.0 * M * N * K / us / 1e6:7.1f} TF')
 
-def run_rownorm(name, M, N, K, ldc):
+def run_rownorm(name, M, N, K, ldc, engines=(0,)):
     """projection with the row norms fused (the step's call) against row-scale from a separate pass"""
     dt = torch.bfloat16
     A = (torch.randn((M, K), device='cuda')).clamp_min_(0).to(dt)
     Bm = (torch.randn((N, K), device='cuda') * 0.02).to(dt)
     bias = torch.randn(N, device='cuda'); inv = torch.empty(M, device='cuda')
     C = torch.empty((M, ldc), device='cuda', dtype=dt)
+    for eng in engines:
+        us = timeit(lambda: call('vqa_gemm_fused_rownorm', ptr(A), K, ptr(Bm), K, ptr(C), ldc, M, N, K, ptr(bias), ptr(inv), 0, 1, 1, eng))
+        print(f'{name:10s} fused row norms engine={eng} ldc={ldc}: {us:8.1f} us  {2.0 * M * N * K / us / 1e6:7.1f} TF')
     for label, fn in (('fused row norms', lambda: call('vqa_gemm_fused_rownorm', ptr(A), K, ptr(Bm), K, ptr(C), ldc, M, N, K, ptr(bias), ptr(inv), 0, 1, 1, 0)),
                       ('row scale given', lambda: call('vqa_gemm_fused', ptr(A), K, 1, ptr(Bm), K, 1, ptr(C), ldc, M, N, K, ptr(bias), ptr(inv), 0, 1, 1, 0)),
                       ('inv_norm pass  ', lambda: call('vqa_inv_norm', ptr(A), ptr(inv), M, K, K, 1))):
@@ -51,7 +54,7 @@ def run(name, M, N, K, akm, bkm, variants, ldb=None):
     slab = torch.empty(max(v[1] for v in variants) * M * N, device='cuda', dtype=torch.float32)
     for eng, sk in variants:
         us = timeit(lambda: call('vqa_gemm_slabs', ptr(A), lda, int(akm), ptr(Bm), ldb, int(bkm), ptr(slab), M * N, N, M, N, K, sk, 1, eng))
-        print(f'{name:12s} M={M:6d} N={N:5d} K={K:6d} tile={ {2: "64", 3: "128", 4: "256x128", 6: "256x256", 8: "256x256r10", 9: "256x256r10pf", 10: "256x256pp"}[eng] } splitk={sk:2d}: {us:8.1f} us  {2.0 * M * N * K / us / 1e6:7.1f} TF')
+        print(f'{name:12s} M={M:6d} N={N:5d} K={K:6d} tile={ {2: "64", 3: "128", 4: "256x128", 6: "256x256", 8: "256x256r10", 9: "256x256r10pf", 10: "256x256pp", 11: "256x256sp"}[eng] } splitk={sk:2d}: {us:8.1f} us  {2.0 * M * N * K / us / 1e6:7.1f} TF')
 
 def run_pitch():
     """Does the operand pitch matter (power-of-two row pitch = every row of a tile column on one memory channel)?"""
@@ -93,6 +96,17 @@ if __name__ == '__main__':
             run('K4 fwd NT', 50176, 1200, 2048, True, True, [(10, 1)])
             run('sq4k', 4096, 4096, 4096, True, True, [(10, 1)])
             run('square', 8192, 8192, 8192, True, True, [(10, 1)])
+    elif which == 'sp':
+        for _ in range(3):
+            run('K4 fwd NT', 50176, 1200, 2048, True, True, [(10, 1), (11, 1)])
+            run_fused('K4 fwd', 50176, 1200, 2048, [10, 11], ldc=1280)
+            run('sq4k', 4096, 4096, 4096, True, True, [(10, 1), (11, 1)])
+            run('square', 8192, 8192, 8192, True, True, [(10, 1), (11, 1)])
+            run('wgrad TN sw ld1280', 2048, 1200, 50176, False, False, [(10, 6), (11, 6)], ldb=1280)
+    elif which == 'spn':
+        for _ in range(3):
+            run_rownorm('K4 fwd', 50176, 1200, 2048, 1280, engines=(10, 11))
+            run('wgrad TN sw ld1280', 2048, 1200, 50176, False, False, [(10, 6), (11, 5), (11, 6), (11, 7), (11, 8)], ldb=1280)
     elif which == 'pitch':
         run_pitch()
     elif which == 'wg':

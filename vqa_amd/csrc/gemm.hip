@@ -1020,6 +1020,197 @@ k_gemm_bf16_pp(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__
     pp_store<NTS>(acc, epi, split, m0, wm * 128, n0 + wn * 64, M, N, lane, rs_tile, perm);
 }
 
+// ---- 256 x 256 tiles, fragments prefetched under the wave's own MFMAs, two barriers per K tile ----------
+// Same workgroup tile, wave layout (2 x 4 waves of 128 x 64), quarter images, DMA source permutation and register-direct
+// epilogue as the eight-phase kernel above, but a wave does not alternate read phases and MFMA phases with its SIMD
+// partner: a K tile is 16 units of {one 16-row A fragment, 4 MFMAs against the four B fragments held in registers},
+// and while unit u multiplies, the A fragment of unit u + 4 is requested into a ring of eight fragment registers and
+// the B fragments of the next K sub-step into the registers the previous sub-step has released.  A fragment read is
+// therefore always four units (16 MFMAs of this wave, 32 with the partner's) older than its first use, no read is
+// waited for behind a barrier, and the LDS sees a steady stream of reads instead of a burst per phase.
+// LDS: five pairs of 16 KiB quarters.  A(t) (both row quarters of K tile t) lives in pair t % 5, B(t) in pair
+// (t + 2) % 5.  Two barriers per K tile:
+//   X_t (unit 0): every wave has consumed all A fragments of tile t - 1  ->  B(t + 2) is requested into that pair;
+//   Y_t (unit 9): every wave has consumed all B fragments of tile t, and (counted wait, then barrier) tile t + 1 has
+//                 landed  ->  A(t + 2) is requested into B(t)'s pair; reads of tile t + 1 start at unit 10.
+// B(t + 2) is in flight for 1.5 tile times, A(t + 2) for one; the DMA instructions go out one per unit.
+// The LDS-DMA of this kernel is issued from inline assembly: the compiler's wait-count pass books the builtin as an
+// access to both memory and LDS, after which every wait it inserts for an LDS read becomes lgkmcnt(0) -- a full drain
+// of the prefetched fragments four times per K tile.  Written this way it counts the LDS reads exactly; the DMA is
+// waited for by hand (the counted vmcnt at Y_t).
+template <bool KM>
+__device__ __forceinline__ void sp_issue_one(const bf16_t* const (&src)[2], size_t koff, unsigned quarter_lds, int wave, int ld, int which) {
+    const bf16_t* p = KM ? src[which] + koff : src[0] + koff + (size_t)which * 4 * (size_t)ld;
+    const unsigned dst = quarter_lds + (unsigned)((wave * 2 + which) * 1024);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(dst), "v"(p) : "memory", "m0");
+}
+
+template <bool AKM, bool BKM, bool NTS = false, bool NORM = false>
+__global__ void __launch_bounds__(512)
+k_gemm_bf16_sp(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, int M, int N, int K,
+               int tiles_m, int tiles_n, int k_per_split, Epi epi) {
+    constexpr int BM = 256, NW = 8, QB = 16384, NP = 5, D = 4;
+    typedef Tile<128, AKM> TA;
+    typedef Tile<128, BKM> TB;
+    static_assert(TA::BYTES == QB && TB::BYTES == QB, "quarter size");
+    static_assert(!NORM || AKM, "row norms come from k-major A fragments");
+    __shared__ __attribute__((aligned(1024))) char lds[2 * NP * QB];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wm = wave >> 2, wn = wave & 3;
+    int tiles;
+    const int L = logical_block(epi, BM, tiles_m, tiles_n, true, tiles);
+    if (L < 0) return;
+    const int split = L / tiles, ti = L % tiles;
+    const int m0 = (ti / tiles_n) * BM, n0 = (ti % tiles_n) * 256;
+    const int kbeg = split * k_per_split;
+    const int kend = min(K, kbeg + k_per_split);
+    const int nk = kend > kbeg ? (kend - kbeg) / GEMM_BK : 0;          // the launcher guarantees whole K tiles
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const bf16_t* sa0[2]; const bf16_t* sa1[2]; const bf16_t* sb0[2]; const bf16_t* sb1[2];
+    dma_setup<128, AKM, NW>(A, lda, m0, M, wave, lane, sa0);
+    dma_setup<128, AKM, NW>(A, lda, m0 + 128, M, wave, lane, sa1);
+    const bool perm = BKM && epi.out_bf16;                 // column permutation of the register-direct bf16 epilogue (pp_sigma)
+    if (BKM) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int r, c;
+            TB::slot(wave * 2 + i, lane, r, c);
+            const int rr = perm ? (r & 64) + pp_sigma(r & 63) : r;
+            sb0[i] = B + (size_t)min(n0 + rr, N - 1) * ldb + c * 8;
+            sb1[i] = B + (size_t)min(n0 + 128 + rr, N - 1) * ldb + c * 8;
+        }
+    } else {
+        dma_setup<128, BKM, NW>(B, ldb, n0, N, wave, lane, sb0);
+        dma_setup<128, BKM, NW>(B, ldb, n0 + 128, N, wave, lane, sb1);
+    }
+    const size_t ka = AKM ? 1 : (size_t)lda, kb = BKM ? 1 : (size_t)ldb;
+    const int bc = (wn & 1) * 64;
+    const PpMLane ml = pp_m_lane(lane);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+
+    // instruction e (0..3) of the two quarters of tile t's A / B pair
+    auto issue_a = [&](int t, int pair, int e) {
+        if (t >= nk) return;
+        const unsigned q = lds0 + (unsigned)((pair * 2 + (e >> 1)) * QB);
+        const size_t koff = (size_t)(kbeg + t * GEMM_BK) * ka;
+        if (e >> 1) sp_issue_one<AKM>(sa1, koff, q, wave, lda, e & 1); else sp_issue_one<AKM>(sa0, koff, q, wave, lda, e & 1);
+    };
+    auto issue_b = [&](int t, int pair, int e) {
+        if (t >= nk) return;
+        const unsigned q = lds0 + (unsigned)((pair * 2 + (e >> 1)) * QB);
+        const size_t koff = (size_t)(kbeg + t * GEMM_BK) * kb;
+        if (e >> 1) sp_issue_one<BKM>(sb1, koff, q, wave, ldb, e & 1); else sp_issue_one<BKM>(sb0, koff, q, wave, ldb, e & 1);
+    };
+    // fragment of the 16 tile rows from r0 of the quarter whose LDS byte offset (from lds[0]) is qo
+    auto read_a = [&](int qo, int r0, int kk) -> bf16x8_t {
+        if (AKM) return frag_read<128, true>(lds + qo, r0, kk, lane);
+        return pp_frag_m(lds0 + qo + ml.L, ml.X, r0, kk);
+    };
+    auto read_b = [&](int qo, int r0, int kk) -> bf16x8_t {
+        if (BKM) return frag_read<128, true>(lds + qo, r0, kk, lane);
+        return pp_frag_m(lds0 + qo + ml.L, ml.X, r0, kk);
+    };
+    auto next = [](int p) { return p == NP - 1 ? 0 : p + 1; };
+
+    bf16x8_t fa[8], fb[2][4];
+    // NORM: the four column-waves that share 128 A rows square two of the eight 16-row fragments each (2 wn, 2 wn + 1)
+    // as they pass through the fragment ring: four v_dot2 behind the unit's MFMAs, in 4 of a wave's 16 units per tile
+    float ss[2] = {0.f, 0.f};
+#define SP_SQ(V, PR, ACC)                                                                                       \
+    ACC = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(V, V, 2 * (PR), 2 * (PR) + 1),                \
+                                          __builtin_shufflevector(V, V, 2 * (PR), 2 * (PR) + 1), ACC, false)
+    // prologue: tiles 0 and 1 (pairs: A(0) 0, A(1) 1, B(0) 2, B(1) 3)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) issue_b(0, 2, e);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) issue_a(0, 0, e);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) issue_b(1, 3, e);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) issue_a(1, 1, e);
+    if (nk >= 2) { VMCNT_BARRIER(8); } else { VMCNT_BARRIER(0); }
+    if (nk > 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[0][j] = read_b((2 * 2 + (wn >> 1)) * QB, bc + j * 16, 0);
+#pragma unroll
+        for (int u = 0; u < D; ++u) fa[u] = read_a((0 * 2 + wm) * QB, u * 16, 0);
+    }
+
+    int pa = 0;                                              // pair of A(t)
+    // One K tile.  H1: tile t + 1 exists, H2: tile t + 2 exists (compile-time, so that the steady-state loop body is
+    // straight-line code: the last two tiles are peeled).
+#define SP_UNIT(U)                                                                                              \
+        {                                                                                                       \
+            constexpr int kk = (U) >> 3, i = (U) & 7, un = (U) + D;                                             \
+            if ((U) == 0) __builtin_amdgcn_s_barrier();                          /* X_t */                      \
+            if ((U) == 9) {                                                      /* Y_t */                      \
+                if (H2) { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }                                    \
+                else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }                                       \
+                __builtin_amdgcn_s_barrier();                                                                   \
+            }                                                                                                   \
+            if (un < 16) fa[un & 7] = read_a(qa_cur, (un & 7) * 16, un >> 3);                                   \
+            else if (H1) fa[un & 7] = read_a(qa_nxt, (un & 7) * 16, 0);                                         \
+            if ((U) < 4) fb[1][(U) & 3] = read_b(qb_cur, bc + ((U) & 3) * 16, 1);                               \
+            if ((U) >= 10 && (U) < 14 && H1) fb[0][((U) - 10) & 3] = read_b(qb_nxt, bc + (((U) - 10) & 3) * 16, 0); \
+            if ((U) < 4 && H2) issue_b(t + 2, pb2, (U) & 3);                                                    \
+            if ((U) >= 9 && (U) < 13 && H2) issue_a(t + 2, pb0, ((U) - 9) & 3);                                 \
+            __builtin_amdgcn_sched_barrier(0);                                                                  \
+            __builtin_amdgcn_s_setprio(1);                                                                      \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                       \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[kk][j], fa[(U) & 7], acc[i][j], 0, 0, 0); \
+            __builtin_amdgcn_s_setprio(0);                                                                      \
+            if (NORM && (i >> 1) == wn) {      /* (the empty asm keeps this a scalar branch: if-converted, every wave */ \
+                asm volatile("" ::: "memory");  /*  would square every fragment and select afterwards)           */ \
+                SP_SQ(fa[(U) & 7], 0, ss[i & 1]); SP_SQ(fa[(U) & 7], 1, ss[i & 1]);                             \
+                SP_SQ(fa[(U) & 7], 2, ss[i & 1]); SP_SQ(fa[(U) & 7], 3, ss[i & 1]);                             \
+            }                                                                                                   \
+            __builtin_amdgcn_sched_barrier(0);                                                                  \
+        }
+    auto tile = [&](int t, auto h1, auto h2) {
+        constexpr bool H1 = decltype(h1)::value, H2 = decltype(h2)::value;
+        const int pa1 = next(pa), pb0 = next(pa1), pb1 = next(pb0), pb2 = next(pb1);   // A(t+1), B(t) [= A(t+2)], B(t+1), B(t+2) [= A(t-1)]
+        const int qa_cur = (pa * 2 + wm) * QB, qa_nxt = (pa1 * 2 + wm) * QB;
+        const int qb_cur = (pb0 * 2 + (wn >> 1)) * QB, qb_nxt = (pb1 * 2 + (wn >> 1)) * QB;
+        SP_UNIT(0) SP_UNIT(1) SP_UNIT(2) SP_UNIT(3) SP_UNIT(4) SP_UNIT(5) SP_UNIT(6) SP_UNIT(7)
+        SP_UNIT(8) SP_UNIT(9) SP_UNIT(10) SP_UNIT(11) SP_UNIT(12) SP_UNIT(13) SP_UNIT(14) SP_UNIT(15)
+        pa = pa1;
+    };
+#undef SP_UNIT_KEEP
+    int t = 0;
+    for (; t + 2 < nk; ++t) tile(t, std::true_type{}, std::true_type{});
+    if (t + 1 < nk) { tile(t, std::true_type{}, std::false_type{}); ++t; }
+    if (t < nk) tile(t, std::false_type{}, std::false_type{});
+#undef SP_UNIT
+#undef SP_SQ
+    const float* rs_tile = nullptr;
+    if (NORM) {
+        VMCNT_BARRIER(0);    // every wave is done with the ring before its first bytes take the row scales
+        float* rs = reinterpret_cast<float*>(lds);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            float v = ss[e];                                // a lane holds 8 of its row's 32 k's per sub-step
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            const float inv = 1.0f / fmaxf(sqrtf(v), 1e-12f);
+            const int row = wm * 128 + (2 * wn + e) * 16 + (lane & 15);
+            if (lane < 16) {
+                rs[row] = inv;
+                if (n0 == 0 && m0 + row < M) epi.norm_out[m0 + row] = inv;
+            }
+        }
+        __syncthreads();
+        rs_tile = rs;
+    }
+    pp_store<NTS>(acc, epi, split, m0, wm * 128, n0 + wn * 64, M, N, lane, rs_tile, perm);
+}
+
 // ---- fp32 / any-stride VALU kernel -----------------------------------------------
 template <typename T, bool AKM, bool BKM>
 __global__ void __launch_bounds__(256)
@@ -1082,7 +1273,8 @@ enum TileEngine {
     TILE_256_W8,          // 256 x 256, 8 waves, two-slot ring (k_gemm_bf16_w8<256>)
     TILE_256_R10,         // 256 x 256, ring of ten quarter-operand slots (k_gemm_bf16_r10<PF = 0>)
     TILE_256_R10PF,       // same, all fragments of a K tile read before its MFMAs (k_gemm_bf16_r10<PF = 1>)
-    TILE_256_PP           // 256 x 256, eight-phase schedule with staggered wave groups (k_gemm_bf16_pp)
+    TILE_256_PP,          // 256 x 256, eight-phase schedule with staggered wave groups (k_gemm_bf16_pp)
+    TILE_256_SP           // 256 x 256, fragments prefetched under the wave's own MFMAs (k_gemm_bf16_sp)
 };
 static inline bool tile_is_256sq(int t) { return t >= TILE_256_W8; }
 static inline int tile_rows(int t) { return t == TILE_64 ? 64 : t == TILE_128 ? 128 : 256; }
@@ -1090,7 +1282,7 @@ static inline int tile_cols(int t) { return t == TILE_64 ? 64 : (t == TILE_128 |
 
 // tile choice shared by the launcher and the split-K hint: 128x128 workgroup tiles when the
 // output has enough of them, 64x64 otherwise; the `engine` argument of the entry points forces one:
-// 2 / 3 / 4 / 6 / 8 / 9 / 10 in the order of TileEngine (0 = choose, 1 = the VALU kernel)
+// 2 / 3 / 4 / 6 / 8 / 9 / 10 / 11 in the order of TileEngine (0 = choose, 1 = the VALU kernel)
 static inline int pick_tile(int M, int N, int K, int akm, int bkm, int engine) {
     if (engine == 2) return TILE_64;
     if (engine == 3) return TILE_128;
@@ -1099,6 +1291,7 @@ static inline int pick_tile(int M, int N, int K, int akm, int bkm, int engine) {
     if (engine == 8) return TILE_256_R10;
     if (engine == 9) return TILE_256_R10PF;
     if (engine == 10) return TILE_256_PP;
+    if (engine == 11) return TILE_256_SP;
     const long t128 = (long)ceil_div(M, 128) * ceil_div(N, 128);
     const long t256 = (long)ceil_div(M, 256) * ceil_div(N, 128);
     const long t512 = (long)ceil_div(M, 256) * ceil_div(N, 256);
@@ -1144,6 +1337,17 @@ static inline bool use_eight_phase() {
 #endif
 }
 
+// Of the two full-LDS 256 x 256 schedules the prefetching one (k_gemm_bf16_sp) is the default; engine 10 asks for the
+// eight-phase kernel (development builds: VQA_GEMM_SP=0 does so for every product)
+static inline bool use_prefetch_engine() {
+#ifdef VQA_DEV
+    static const bool on = [] { const char* e = getenv("VQA_GEMM_SP"); return !e || atoi(e) != 0; }();
+    return on;
+#else
+    return true;
+#endif
+}
+
 static int launch_bf16(const void* A, int lda, int akm, const void* B, int ldb, int bkm, int M, int N, int K,
                        int splitk, int engine, const Epi& epi, hipStream_t stream) {
     int kps = ceil_div(ceil_div(K, splitk), GEMM_BK) * GEMM_BK;
@@ -1151,14 +1355,27 @@ static int launch_bf16(const void* A, int lda, int akm, const void* B, int ldb, 
     // when there are many row tiles (a packed batch of sequences), for all of them otherwise
     const int m_sched = (epi.m_limit && M >= 1024) ? M / 2 : M;
     int bm = pick_tile(m_sched, N, K, akm, bkm, engine);
-    if (engine == 0 && (bm == TILE_256_R10PF || bm == TILE_256_W8) && use_eight_phase()) bm = TILE_256_PP;   // (falls back below when the shape does not fit)
+    if (engine == 0 && (bm == TILE_256_R10PF || bm == TILE_256_W8) && use_eight_phase())
+        bm = use_prefetch_engine() ? TILE_256_SP : TILE_256_PP;                  // (falls back below when the shape does not fit)
     const bool big = bm == TILE_128;
     const int tm = ceil_div(M, tile_rows(bm)), tn = ceil_div(N, tile_cols(bm));
     const unsigned grid = (unsigned)(tm * tn * splitk);
     const bf16_t* a = (const bf16_t*)A; const bf16_t* b = (const bf16_t*)B;
     // the eight-phase kernel takes whole K tiles, no device-side limits, and bf16 output only with a k-major B
-    if (bm == TILE_256_PP && (kps % GEMM_BK || K % GEMM_BK || epi.m_limit || epi.k_limit || (epi.out_bf16 && !bkm)))
+    if ((bm == TILE_256_PP || bm == TILE_256_SP) && (kps % GEMM_BK || K % GEMM_BK || epi.m_limit || epi.k_limit || (epi.out_bf16 && !bkm)))
         return launch_bf16(A, lda, akm, B, ldb, bkm, M, N, K, splitk, (akm && bkm) ? 9 : 6, epi, stream);
+    if (bm == TILE_256_SP) {
+        const bool nts = want_nt_store(epi, M, N, splitk);
+#define LAUNCHS(AK, BK_)                                                                                              \
+    do { if (nts) k_gemm_bf16_sp<AK, BK_, true><<<grid, 512, 0, stream>>>(a, lda, b, ldb, M, N, K, tm, tn, kps, epi); \
+         else k_gemm_bf16_sp<AK, BK_, false><<<grid, 512, 0, stream>>>(a, lda, b, ldb, M, N, K, tm, tn, kps, epi); } while (0)
+        if (akm && bkm) LAUNCHS(true, true);
+        else if (akm && !bkm) LAUNCHS(true, false);
+        else if (!akm && bkm) LAUNCHS(false, true);
+        else LAUNCHS(false, false);
+#undef LAUNCHS
+        return 0;
+    }
     if (bm == TILE_256_PP) {
         const bool nts = want_nt_store(epi, M, N, splitk);
 #define LAUNCHP(AK, BK_)                                                                                              \
@@ -1358,17 +1575,21 @@ int vqa_gemm_fused_rownorm(const void* A, int lda, const void* B, int ldb, void*
     VQA_REQUIRE(act == 0 || act == 1, "vqa_gemm_fused_rownorm: act must be 0 (none) or 1 (tanh)");
     VQA_REQUIRE(out_dtype == VQA_F32 || out_dtype == VQA_BF16, "vqa_gemm_fused_rownorm: out_dtype");
     const int bm = (dtype == VQA_BF16 && engine != 1) ? pick_tile(M, N, K, 1, 1, engine) : TILE_64;
-    if (bm == TILE_256_R10 || bm == TILE_256_R10PF || bm == TILE_256_PP) {
+    if (bm == TILE_256_R10 || bm == TILE_256_R10PF || bm == TILE_256_PP || bm == TILE_256_SP) {
         Epi epi{C, ldc, out_dtype == VQA_BF16, 0, bias, nullptr, act, nullptr, nullptr, inv_norm};
         const int tm = ceil_div(M, 256), tn = ceil_div(N, 256);
         const int kps = ceil_div(K, GEMM_BK) * GEMM_BK;
         if (use_eight_phase() && K % GEMM_BK == 0) {
-            if (want_nt_store(epi, M, N, 1))
-                k_gemm_bf16_pp<true, true, true, true><<<(unsigned)(tm * tn), 512, 0, stream>>>(
-                    (const bf16_t*)A, lda, (const bf16_t*)B, ldb, M, N, K, tm, tn, kps, epi);
-            else
-                k_gemm_bf16_pp<true, true, true, false><<<(unsigned)(tm * tn), 512, 0, stream>>>(
-                    (const bf16_t*)A, lda, (const bf16_t*)B, ldb, M, N, K, tm, tn, kps, epi);
+            const bool nts = want_nt_store(epi, M, N, 1);
+            const unsigned grid = (unsigned)(tm * tn);
+            const bf16_t* a = (const bf16_t*)A; const bf16_t* b = (const bf16_t*)B;
+            if (bm == TILE_256_PP || !use_prefetch_engine()) {
+                if (nts) k_gemm_bf16_pp<true, true, true, true><<<grid, 512, 0, stream>>>(a, lda, b, ldb, M, N, K, tm, tn, kps, epi);
+                else k_gemm_bf16_pp<true, true, true, false><<<grid, 512, 0, stream>>>(a, lda, b, ldb, M, N, K, tm, tn, kps, epi);
+            } else {
+                if (nts) k_gemm_bf16_sp<true, true, true, true><<<grid, 512, 0, stream>>>(a, lda, b, ldb, M, N, K, tm, tn, kps, epi);
+                else k_gemm_bf16_sp<true, true, false, true><<<grid, 512, 0, stream>>>(a, lda, b, ldb, M, N, K, tm, tn, kps, epi);
+            }
             return vqa_check_launch("vqa_gemm_fused_rownorm");
         }
         k_gemm_bf16_r10<true, true, 0, true><<<(unsigned)(tm * tn), 512, 0, stream>>>(
