@@ -22,9 +22,9 @@ clean:
 # Development build for A/B and probe runs on the GPU box: environment switches (VQA_GEMM_NT, VQA_GEMM_PP) and,
 # with PP_PROBE=1..4, the timing probes of the eight-phase GEMM (wrong results by construction).  Never loaded by
 # the package unless VQA_HIP_LIB points at it.
-DEVDIR := build/dev
+DEVDIR ?= build/dev
 DEVOBJ := $(patsubst vqa_amd/csrc/%.hip,$(DEVDIR)/%.o,$(SRC))
-DEVFLAGS := -DVQA_DEV $(if $(PP_PROBE),-DPP_PROBE=$(PP_PROBE))
+DEVFLAGS := -DVQA_DEV $(if $(PP_PROBE),-DPP_PROBE=$(PP_PROBE)) $(EXTRA)
 DEVLIB ?= vqa_amd/libvqa_hip_dev.so
 
 $(DEVDIR)/%.o: vqa_amd/csrc/%.hip $(HDR)

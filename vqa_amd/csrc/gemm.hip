@@ -732,9 +732,11 @@ __device__ __forceinline__ int pp_sigma(int p) {
 // Accumulators -> global straight from the registers (no LDS staging, no barrier): bf16 output as 16-byte stores of 8
 // consecutive columns (16 rows x 64 bytes per store instruction), fp32 output as 16-byte stores of a fragment's 4
 // columns (16 rows x 64 bytes).  m_w: first row of the wave's 128 inside the tile; n_w: the wave's first column.
+// rot: acc[i] holds the wave's 16-row block (i + rot) & 7 (the prefetching kernel rotates the order in which a wave
+// walks its row blocks; 0 = identity).
 template <bool NTS>
 __device__ __forceinline__ void pp_store(f32x4 (&acc)[8][4], const Epi& epi, int split, int m0, int m_w, int n_w, int M, int N,
-                                         int lane, const float* rs_tile, bool perm) {
+                                         int lane, const float* rs_tile, bool perm, int rot = 0) {
     const int g = lane >> 4, c = lane & 15;
     const bool vec_ok = ((((size_t)epi.ld * (epi.out_bf16 ? 2 : 4)) & 15) == 0) && ((((uintptr_t)epi.out) & 15) == 0) &&
                         (((epi.split_stride * 4) & 15) == 0);
@@ -751,9 +753,10 @@ __device__ __forceinline__ void pp_store(f32x4 (&acc)[8][4], const Epi& epi, int
         bf16_t* out = (bf16_t*)epi.out;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int m = m0 + m_w + 16 * i + c;
+            const int rb = 16 * ((i + rot) & 7);
+            const int m = m0 + m_w + rb + c;
             if (m >= M) continue;
-            const float rs = rs_tile ? rs_tile[m_w + 16 * i + c] : (epi.row_scale ? epi.row_scale[m] : 1.f);
+            const float rs = rs_tile ? rs_tile[m_w + rb + c] : (epi.row_scale ? epi.row_scale[m] : 1.f);
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int n = n_w + 32 * h + 8 * g;
@@ -785,9 +788,10 @@ __device__ __forceinline__ void pp_store(f32x4 (&acc)[8][4], const Epi& epi, int
         }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const int m = m0 + m_w + 16 * i + c;
+        const int rb = 16 * ((i + rot) & 7);
+        const int m = m0 + m_w + rb + c;
         if (m >= M) continue;
-        const float rs = rs_tile ? rs_tile[m_w + 16 * i + c] : (epi.row_scale ? epi.row_scale[m] : 1.f);
+        const float rs = rs_tile ? rs_tile[m_w + rb + c] : (epi.row_scale ? epi.row_scale[m] : 1.f);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int n = n_w + 16 * j + 4 * g;
@@ -1049,7 +1053,24 @@ template <bool AKM, bool BKM, bool NTS = false, bool NORM = false>
 __global__ void __launch_bounds__(512)
 k_gemm_bf16_sp(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, int M, int N, int K,
                int tiles_m, int tiles_n, int k_per_split, Epi epi) {
-    constexpr int BM = 256, NW = 8, QB = 16384, NP = 5, D = 4;
+    // development-build knobs (A/B runs): prefetch distance, one barrier per tile, no priority raise
+#if defined(VQA_DEV) && defined(SP_D)
+    constexpr int D = SP_D;
+#else
+    constexpr int D = 4;
+#endif
+#if defined(VQA_DEV) && defined(SP_ONEBAR)
+    constexpr bool ONEBAR = true;
+#else
+    constexpr bool ONEBAR = false;
+#endif
+#if defined(VQA_DEV) && defined(SP_NOPRIO)
+    constexpr int PRIO = 0;
+#else
+    constexpr int PRIO = 1;
+#endif
+    static_assert(D >= 1 && D <= 7, "a fragment must not be overwritten before its unit has used it");
+    constexpr int BM = 256, NW = 8, QB = 16384, NP = 5;
     typedef Tile<128, AKM> TA;
     typedef Tile<128, BKM> TB;
     static_assert(TA::BYTES == QB && TB::BYTES == QB, "quarter size");
@@ -1120,12 +1141,18 @@ k_gemm_bf16_sp(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__
     auto next = [](int p) { return p == NP - 1 ? 0 : p + 1; };
 
     bf16x8_t fa[8], fb[2][4];
-    // NORM: the four column-waves that share 128 A rows square two of the eight 16-row fragments each (2 wn, 2 wn + 1)
-    // as they pass through the fragment ring: four v_dot2 behind the unit's MFMAs, in 4 of a wave's 16 units per tile
-    float ss[2] = {0.f, 0.f};
-#define SP_SQ(V, PR, ACC)                                                                                       \
-    ACC = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(V, V, 2 * (PR), 2 * (PR) + 1),                \
-                                          __builtin_shufflevector(V, V, 2 * (PR), 2 * (PR) + 1), ACC, false)
+    // NORM: the four column-waves that share 128 A rows take the squared norms of two of the eight 16-row blocks each
+    // (2 wn, 2 wn + 1) as the fragments pass through the ring, on the matrix cores: one more MFMA of the fragment
+    // against itself per unit, whose 16 x 16 result has the rows' sums of squares on its diagonal (16 cycles of the
+    // matrix pipe; four v_dot2 per fragment on the vector pipe, which the partner wave's MFMAs also issue through, cost
+    // 20 us of this launch).  So that the squaring units are the same in every wave (a test of the wave id in each unit
+    // costs a scalar branch per unit: 16 per K tile), a wave walks its eight row blocks starting from block 2 wn:
+    // unit i works on block (i + 2 wn) & 7, and units 0 and 1 of each sub-step square.  Without NORM: the identity.
+    const int rot = NORM ? 2 * wn : 0;
+    int r0s[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r0s[i] = NORM ? ((i + rot) & 7) * 16 : i * 16;
+    f32x4 gram[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     // prologue: tiles 0 and 1 (pairs: A(0) 0, A(1) 1, B(0) 2, B(1) 3)
 #pragma unroll
     for (int e = 0; e < 4; ++e) issue_b(0, 2, e);
@@ -1140,7 +1167,7 @@ k_gemm_bf16_sp(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__
 #pragma unroll
         for (int j = 0; j < 4; ++j) fb[0][j] = read_b((2 * 2 + (wn >> 1)) * QB, bc + j * 16, 0);
 #pragma unroll
-        for (int u = 0; u < D; ++u) fa[u] = read_a((0 * 2 + wm) * QB, u * 16, 0);
+        for (int u = 0; u < D; ++u) fa[u] = read_a((0 * 2 + wm) * QB, r0s[u], 0);
     }
 
     int pa = 0;                                              // pair of A(t)
@@ -1149,28 +1176,26 @@ k_gemm_bf16_sp(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__
 #define SP_UNIT(U)                                                                                              \
         {                                                                                                       \
             constexpr int kk = (U) >> 3, i = (U) & 7, un = (U) + D;                                             \
-            if ((U) == 0) __builtin_amdgcn_s_barrier();                          /* X_t */                      \
+            if ((U) == 0 && !ONEBAR) __builtin_amdgcn_s_barrier();               /* X_t */                      \
             if ((U) == 9) {                                                      /* Y_t */                      \
-                if (H2) { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }                                    \
+                if (H2 && !ONEBAR) { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }                         \
                 else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }                                       \
                 __builtin_amdgcn_s_barrier();                                                                   \
             }                                                                                                   \
-            if (un < 16) fa[un & 7] = read_a(qa_cur, (un & 7) * 16, un >> 3);                                   \
-            else if (H1) fa[un & 7] = read_a(qa_nxt, (un & 7) * 16, 0);                                         \
+            if (un < 16) fa[un & 7] = read_a(qa_cur, r0s[un & 7], un >> 3);                                     \
+            else if (H1) fa[un & 7] = read_a(qa_nxt, r0s[un & 7], 0);                                           \
             if ((U) < 4) fb[1][(U) & 3] = read_b(qb_cur, bc + ((U) & 3) * 16, 1);                               \
             if ((U) >= 10 && (U) < 14 && H1) fb[0][((U) - 10) & 3] = read_b(qb_nxt, bc + (((U) - 10) & 3) * 16, 0); \
-            if ((U) < 4 && H2) issue_b(t + 2, pb2, (U) & 3);                                                    \
+            if (!ONEBAR && (U) < 4 && H2) issue_b(t + 2, pb2, (U) & 3);                                         \
+            if (ONEBAR && (U) >= 9 && (U) < 13 && H2) issue_b(t + 2, pb2, ((U) - 9) & 3);                       \
             if ((U) >= 9 && (U) < 13 && H2) issue_a(t + 2, pb0, ((U) - 9) & 3);                                 \
             __builtin_amdgcn_sched_barrier(0);                                                                  \
-            __builtin_amdgcn_s_setprio(1);                                                                      \
+            if (PRIO) __builtin_amdgcn_s_setprio(1);                                                            \
             _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                       \
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[kk][j], fa[(U) & 7], acc[i][j], 0, 0, 0); \
-            __builtin_amdgcn_s_setprio(0);                                                                      \
-            if (NORM && (i >> 1) == wn) {      /* (the empty asm keeps this a scalar branch: if-converted, every wave */ \
-                asm volatile("" ::: "memory");  /*  would square every fragment and select afterwards)           */ \
-                SP_SQ(fa[(U) & 7], 0, ss[i & 1]); SP_SQ(fa[(U) & 7], 1, ss[i & 1]);                             \
-                SP_SQ(fa[(U) & 7], 2, ss[i & 1]); SP_SQ(fa[(U) & 7], 3, ss[i & 1]);                             \
-            }                                                                                                   \
+            if (NORM && i < 2)   /* the fragment against itself: the diagonal of the 16 x 16 result sums the squares */ \
+                gram[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[(U) & 7], fa[(U) & 7], gram[i], 0, 0, 0);  \
+            if (PRIO) __builtin_amdgcn_s_setprio(0);                                                            \
             __builtin_amdgcn_sched_barrier(0);                                                                  \
         }
     auto tile = [&](int t, auto h1, auto h2) {
@@ -1188,19 +1213,19 @@ k_gemm_bf16_sp(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__
     if (t + 1 < nk) { tile(t, std::true_type{}, std::false_type{}); ++t; }
     if (t < nk) tile(t, std::false_type{}, std::false_type{});
 #undef SP_UNIT
-#undef SP_SQ
     const float* rs_tile = nullptr;
     if (NORM) {
         VMCNT_BARRIER(0);    // every wave is done with the ring before its first bytes take the row scales
         float* rs = reinterpret_cast<float*>(lds);
+        // lane (g = lane >> 4, c = lane & 15) holds result rows 4 g .. 4 g + 3 of column c: the diagonal element of
+        // row c sits in the lane with g == c >> 2, register c & 3
+        const int c = lane & 15;
+        if ((lane >> 4) == (c >> 2)) {
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            float v = ss[e];                                // a lane holds 8 of its row's 32 k's per sub-step
-            v += __shfl_xor(v, 16);
-            v += __shfl_xor(v, 32);
-            const float inv = 1.0f / fmaxf(sqrtf(v), 1e-12f);
-            const int row = wm * 128 + (2 * wn + e) * 16 + (lane & 15);
-            if (lane < 16) {
+            for (int e = 0; e < 2; ++e) {
+                const float v = (c & 3) == 0 ? gram[e][0] : (c & 3) == 1 ? gram[e][1] : (c & 3) == 2 ? gram[e][2] : gram[e][3];
+                const float inv = 1.0f / fmaxf(sqrtf(v), 1e-12f);
+                const int row = wm * 128 + (2 * wn + e) * 16 + c;
                 rs[row] = inv;
                 if (n0 == 0 && m0 + row < M) epi.norm_out[m0 + row] = inv;
             }
@@ -1208,7 +1233,7 @@ k_gemm_bf16_sp(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__
         __syncthreads();
         rs_tile = rs;
     }
-    pp_store<NTS>(acc, epi, split, m0, wm * 128, n0 + wn * 64, M, N, lane, rs_tile, perm);
+    pp_store<NTS>(acc, epi, split, m0, wm * 128, n0 + wn * 64, M, N, lane, rs_tile, perm, rot);
 }
 
 // ---- fp32 / any-stride VALU kernel -----------------------------------------------
