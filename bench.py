@@ -167,19 +167,33 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
 
+    def avg_ms(name):
+        ev = model.kernel_events.get(name, [])
+        return (sum(a.elapsed_time(b) for a, b in ev) / len(ev), len(ev)) if ev else (0.0, 0)
+
     diag = None
     try:                                   # diagnostics must never cost the run its result line
-        if world > 1:
+        if world > 1 or args.rccl_single:
             # what the first multi-GPU run needs to explain itself: who took part, what was reduced, what the compute
             # stream waited for, how uneven the ranks were
             props = torch.cuda.get_device_properties(dev)
+            # the three roofline kernels as THIS rank timed them: RCCL's kernels share the CUs with the products they run
+            # beside, so scaling loss shows up here first
             me = {'rank': rank, 'local_rank': local, 'device': torch.cuda.current_device(), 'name': props.name,
-                  'uuid': str(getattr(props, 'uuid', '')), 'ms_per_step': my_elapsed_local / args.steps * 1e3}
+                  'uuid': str(getattr(props, 'uuid', '')), 'ms_per_step': my_elapsed_local / args.steps * 1e3,
+                  'kernel_ms': {'attn_fwd': avg_ms('attn_fwd')[0], 'proj': avg_ms('proj:0')[0],
+                                'wgrad': avg_ms('wgrad:attention.0.linear_va.weight')[0]}}
             everyone = [None] * world
             dist.all_gather_object(everyone, me)
             diag = {'rccl_ranks': everyone,
                     'ms_per_step_min': min(e['ms_per_step'] for e in everyone),
-                    'ms_per_step_max': max(e['ms_per_step'] for e in everyone)}
+                    'ms_per_step_max': max(e['ms_per_step'] for e in everyone),
+                    'kernel_ms_max_over_ranks': {k: max(e['kernel_ms'][k] for e in everyone) for k in me['kernel_ms']},
+                    # what is known about the collectives without extra output: the library version and any
+                    # algorithm / protocol forced through the environment (RCCL picks them per message size otherwise)
+                    'rccl': {'version': '.'.join(str(v) for v in torch.cuda.nccl.version()),
+                             'env': {k: v for k, v in os.environ.items()
+                                     if k.startswith(('NCCL_', 'RCCL_')) or k == 'HSA_ENABLE_IPC_MODE_LEGACY'}}}
         if reducer is not None and reducer.timing:
             launches = reducer.timing.get('launch', [])
             waits = reducer.timing.get('wait', [])
@@ -211,9 +225,6 @@ def main():
         diag = dict(diag or {}, diagnostics_error=repr(exc))
 
     if rank == 0:
-        def avg_ms(name):
-            ev = model.kernel_events.get(name, [])
-            return (sum(a.elapsed_time(b) for a, b in ev) / len(ev), len(ev)) if ev else (0.0, 0)
         k6_ms, k6_n = avg_ms('attn_fwd')
         # algorithmic bytes of the fused attention forward per sample and hop (bf16):
         # P (R*A) + V (R*Dv) + qa (A) + pooled (Dv) at 2 B, inv_norm (R) + p (R) at 4 B
@@ -227,8 +238,8 @@ def main():
         # the two MFMA-bound products: region projection (forward) and its weight gradient, 2 B R Dv A flop each
         gemm_flop = 2.0 * B * R * Dv * A
         gemms = {}
-        for key, label in (('proj:0', 'image projection P = normalize(V) W_va^T + b (k_gemm_bf16_pp, row norms fused)'),
-                           ('wgrad:attention.0.linear_va.weight', 'weight gradient dW_va = dP^T V (k_gemm_bf16_pp, split-K partial sums)')):
+        for key, label in (('proj:0', 'image projection P = normalize(V) W_va^T + b (k_gemm_bf16_sp, row norms fused)'),
+                           ('wgrad:attention.0.linear_va.weight', 'weight gradient dW_va = dP^T V (k_gemm_bf16_sp, split-K partial sums)')):
             ms, n = avg_ms(key)
             if n:
                 tf = gemm_flop / (ms * 1e-3) / 1e12

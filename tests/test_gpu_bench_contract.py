@@ -37,3 +37,22 @@ def test_bench_line_has_the_contract_fields():
     assert c['kind'] == 'port' and c['unit'] == 'samples/s' and c['value'] > 0 and c['cores'] >= 1 and c['sample']
     assert 7.5 < d['loss'] < 8.5                      # ln 3000 = 8.006 at initialisation
     assert d['value_unfolded'] > 0
+
+
+def test_bench_multi_gpu_block_over_one_rank_rccl():
+    """The diagnostics the first multi-GPU run will carry (ranks seen, per-rank kernel timings, collectives and bytes
+    per step, exposed wait, RCCL version), produced here by the one-rank RCCL mode."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '8', '--warmup', '2',
+                          '--rccl-single', '--no-cpu-baseline', '--no-unfolded'],
+                         capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][0])
+    m = d['multi_gpu']
+    assert 'diagnostics_error' not in m, m
+    assert len(m['rccl_ranks']) == 1 and m['rccl_ranks'][0]['rank'] == 0
+    k = m['rccl_ranks'][0]['kernel_ms']
+    assert k['attn_fwd'] > 0 and k['proj'] > 0 and k['wgrad'] > 0
+    assert m['kernel_ms_max_over_ranks']['wgrad'] == k['wgrad']
+    assert m['rccl']['version'].count('.') >= 1
+    c = m['communication']
+    assert c['collectives_per_step'] == 2 and c['allreduce_bytes_per_step'] > 40e6 and c['exposed_wait_ms_per_step'] >= 0
