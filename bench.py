@@ -90,6 +90,7 @@ def main():
     ap.add_argument('--overlap-encoder', action='store_true', help='A/B: frozen question encoder on a second stream beside the region projection')
     ap.add_argument('--no-merge-head', action='store_true',
                     help="A/B: the head's weight / bias gradients in a launch of their own instead of the attention backward's")
+    ap.add_argument('--no-split-attn', action='store_true', help='A/B (batch < #CUs): one attention workgroup per sample')
     ap.add_argument('--no-pad-rows', action='store_true', help='A/B: projected features P / dP with unpadded 2400-byte rows')
     ap.add_argument('--rccl-single', action='store_true',
                     help='N=1 only: run the bucketed all-reduce path over a one-rank RCCL group (its cost without peers)')
@@ -129,6 +130,8 @@ def main():
         model.pad_projection_rows = False
     if args.no_merge_head:
         model.merge_head_group = False
+    if args.no_split_attn:
+        model.split_small_batches = False
     reducer = GradReducer(force=args.rccl_single) if (world > 1 or args.rccl_single) else None
     nb = max(2, min(4, (320 << 20) // (B * R * Dv * 2) + 1))      # > 256 MiB of features in rotation
     batches = synth_batches(nb, B, R, Dv, L, Vq, C, dev, 42 + rank, torch.bfloat16)

@@ -38,8 +38,8 @@ extern "C" {
 
 /* 200: vqa_sequence_pack (+n_table_rows, status), vqa_softmax_ce (+status) and vqa_adam_step (+status) take more
  * arguments than in version 100, and vqa_gemm_slabs_group takes up to 8 products: code built against the version-100
- * header must be rebuilt (vqa_version() tells which library is loaded). */
-#define VQA_HIP_VERSION 200
+ * header must be rebuilt (vqa_version() tells which library is loaded).  210 adds entry points only. */
+#define VQA_HIP_VERSION 210
 #define VQA_F32 0
 #define VQA_BF16 1
 
@@ -185,6 +185,28 @@ int vqa_attn_bwd_dslabs(const void* P, int ldP, const void* V, int ldV, const fl
                         size_t dpool_stride, unsigned drop_seed, float drop_p, float* d_pooled, int ld_dpool, void* dP,
                         int ld_dP, float* dqa_f32, void* dqa_t, int ld_dqa, float* dwa_part, float* dc_part, int B, int R,
                         int A, int Dv, int dtype, hipStream_t stream);
+
+/* Small batches.  The two kernels above run one workgroup per sample; with fewer samples than CUs (the reference's own
+ * batch sizes: train.py:242 bs 40, test.py:120 bs 70) most of the chip idles.  These forms share a sample's region
+ * rows among nsplit workgroups (bf16 storage, the shapes of the streaming kernels):
+ *   forward: every row range keeps a running maximum of its own; a second small launch merges the ranges of a sample in
+ *            index order (same p and pooled up to fp32 rounding of the exponent shifts);
+ *   backward: two launches (the softmax backward needs sum_r p_r dp_r over all rows of the sample in between); the
+ *            per-range sums of dqa come back as nsplit slabs dqa_slabs[range][b][0:A] (reduce them with vqa_epilogue),
+ *            dwa_part has B * nsplit rows and dc_part B * nsplit entries (their consumers sum over rows anyway).
+ * vqa_attn_splits: the nsplit that fills the chip once (1: use the plain entry points); workspace: fp32 scratch of
+ * vqa_attn_split_workspace_floats(B, R, Dv, nsplit) elements shared by the forward and the backward of a step.
+ * No reference counterpart, as above. */
+int vqa_attn_splits(int B, int R, int A, int Dv, int dtype);
+size_t vqa_attn_split_workspace_floats(int B, int R, int Dv, int nsplit);
+int vqa_attn_fwd_split(const void* P, int ldP, const void* V, int ldV, const float* qa, int ld_qa, const float* w_a,
+                       const float* c_a, const float* inv_norm, float* p_out, void* pooled_t, float* pooled_f32,
+                       int ld_pool, int B, int R, int A, int Dv, int dtype, void* pooled_drop, unsigned drop_seed,
+                       float drop_p, int nsplit, float* workspace, hipStream_t stream);
+int vqa_attn_bwd_split(const void* P, int ldP, const void* V, int ldV, const float* qa, int ld_qa, const float* w_a,
+                       const float* inv_norm, const float* p_in, const float* d_pooled, int ld_dpool, void* dP, int ld_dP,
+                       float* dqa_slabs, int ld_dqa, float* dwa_part, float* dc_part, int B, int R, int A, int Dv,
+                       int dtype, int nsplit, float* workspace, hipStream_t stream);
 
 /* ---- feature-map front-ends of the reference's ResNet models (precomputed maps) ------------- */
 

@@ -154,3 +154,82 @@ def test_attention_fed_with_partial_sums_matches_reduced_operands(B, R, A, Dv):
         outs.append((qa, p, pooled, pd, dP, dqa, dqa_t, dwa, dc))
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('B,R,A,Dv', [(40, 196, 1200, 2048), (70, 196, 1200, 2048), (3, 37, 520, 1600), (1, 1000, 64, 128),
+                                      (5, 33, 2048, 512), (17, 576, 1200, 2048)])
+def test_small_batch_row_split_matches_one_workgroup_per_sample(B, R, A, Dv):
+    """vqa_attn_fwd_split / vqa_attn_bwd_split (a sample's rows shared by several workgroups; the reference's own batch
+    sizes are 40 and 70, train.py:242, test.py:120) against fp64 and against the one-workgroup-per-sample kernels, for
+    every split count the shape admits, dropout output included."""
+    from vqa_amd._lib import call, ptr, BF16, F32
+    g = torch.Generator(device='cuda').manual_seed(B * 31 + R)
+    dt = torch.bfloat16
+    P = torch.randn(B, R, A, device='cuda', generator=g).to(dt)
+    V = torch.randn(B, R, Dv, device='cuda', generator=g).clamp_min(0).to(dt)
+    qa = torch.randn(B, A, device='cuda', generator=g)
+    wa = torch.randn(A, device='cuda', generator=g) * (4.0 / A ** 0.5)        # (peaked attention: the maxima of the ranges differ)
+    c = torch.full((1,), 0.25, device='cuda')
+    inv = torch.rand(B, R, device='cuda', generator=g) + 0.5
+    dpool = torch.randn(B, Dv, device='cuda', generator=g)
+    auto = call('vqa_attn_splits', B, R, A, Dv, BF16)
+    assert 1 <= auto <= 8 and (B * auto <= 256 or auto == 1)
+    if (B, R) in ((40, 196), (70, 196)):
+        assert auto == {40: 6, 70: 3}[B]
+    assert call('vqa_attn_splits', 256, R, A, Dv, BF16) == 1 and call('vqa_attn_splits', B, R, A, Dv, F32) == 1
+
+    Pd = P.double().requires_grad_(True)
+    qad = qa.double().requires_grad_(True)
+    wad = wa.double().requires_grad_(True)
+    cd = c.double().requires_grad_(True)
+    p_ref, pooled_ref = _ref(Pd, V, qad, wad, cd, inv)
+    (pooled_ref * dpool.double()).sum().backward()
+
+    def rel(got, ref):
+        return float((got.double() - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+
+    # one workgroup per sample
+    p1 = torch.zeros(B, R, device='cuda'); pooled1 = torch.zeros(B, Dv, device='cuda', dtype=dt); drop1 = torch.zeros_like(pooled1)
+    call('vqa_attn_fwd', ptr(P), A, ptr(V), Dv, ptr(qa), A, ptr(wa), ptr(c), ptr(inv), ptr(p1), ptr(pooled1), None,
+         Dv, B, R, A, Dv, BF16, ptr(drop1), 77, 0.5)
+    dP1 = torch.zeros(B, R, A, device='cuda', dtype=dt)
+    dqa1 = torch.zeros(B, A, device='cuda'); dqat1 = torch.zeros(B, A, device='cuda', dtype=dt)
+    dwa1 = torch.zeros(B, A, device='cuda'); dc1 = torch.zeros(B, device='cuda')
+    call('vqa_attn_bwd', ptr(P), A, ptr(V), Dv, ptr(qa), A, ptr(wa), ptr(inv), ptr(p1), ptr(dpool), Dv, ptr(dP1), A,
+         ptr(dqa1), ptr(dqat1), A, ptr(dwa1), ptr(dc1), B, R, A, Dv, BF16)
+    torch.cuda.synchronize()
+
+    nch = (R + 15) // 16
+    for ns in sorted({2, min(3, nch), min(8, nch), auto} - {1}):
+        if ns > nch:
+            continue
+        wsf = torch.full((call('vqa_attn_split_workspace_floats', B, R, Dv, ns),), float('nan'), device='cuda')
+        p = torch.full((B, R), -1.0, device='cuda')
+        pooled32 = torch.zeros(B, Dv, device='cuda'); pooled = torch.zeros(B, Dv, device='cuda', dtype=dt)
+        drop = torch.zeros_like(pooled)
+        call('vqa_attn_fwd_split', ptr(P), A, ptr(V), Dv, ptr(qa), A, ptr(wa), ptr(c), ptr(inv), ptr(p), ptr(pooled),
+             ptr(pooled32), Dv, B, R, A, Dv, BF16, ptr(drop), 77, 0.5, ns, ptr(wsf))
+        torch.cuda.synchronize()
+        assert torch.allclose(p.double().sum(1), torch.ones(B, device='cuda', dtype=torch.float64), atol=1e-5)
+        assert float((p.double() - p_ref).abs().max()) <= 2e-5 * max(1.0, float(p_ref.max()) * 10), ns
+        assert rel(pooled32, pooled_ref.detach()) <= 2e-5, ns
+        assert torch.equal(pooled, pooled32.to(dt))
+        assert float((pooled.float() - pooled1.float()).abs().max()) <= 1e-2 * float(pooled1.float().abs().max())
+        sep = torch.zeros_like(pooled)
+        call('vqa_dropout', ptr(pooled), Dv, ptr(sep), Dv, B, Dv, 77, 0.5, BF16)
+        torch.cuda.synchronize()
+        assert torch.equal(drop, sep)
+        # backward, from the same probabilities as the one-workgroup run
+        dP = torch.zeros(B, R, A, device='cuda', dtype=dt)
+        slabs = torch.full((ns, B, A), float('nan'), device='cuda')
+        dwa = torch.full((B * ns, A), float('nan'), device='cuda'); dc = torch.full((B * ns,), float('nan'), device='cuda')
+        call('vqa_attn_bwd_split', ptr(P), A, ptr(V), Dv, ptr(qa), A, ptr(wa), ptr(inv), ptr(p1), ptr(dpool), Dv, ptr(dP), A,
+             ptr(slabs), A, ptr(dwa), ptr(dc), B, R, A, Dv, BF16, ns, ptr(wsf))
+        dqa = torch.zeros(B, A, device='cuda'); dqat = torch.zeros(B, A, device='cuda', dtype=dt)
+        call('vqa_epilogue', ptr(slabs), ns, B * A, B, A, None, None, None, 0, 0, ptr(dqa), A, ptr(dqat), A, BF16, 0, 0.0)
+        torch.cuda.synchronize()
+        assert torch.equal(dP, dP1), ns                 # row by row the same arithmetic from the same sums
+        assert rel(dqa, qad.grad) <= 1e-4 and rel(dqa, dqa1.double()) <= 1e-5
+        assert torch.equal(dqat, dqa.to(dt))
+        assert rel(dwa.sum(0), wad.grad) <= 1e-4 and rel(dwa.sum(0), dwa1.double().sum(0)) <= 1e-5
+        assert abs(float(dc.double().sum()) - float(dc1.double().sum())) <= 1e-4 * max(1.0, float(dpool.abs().max()))

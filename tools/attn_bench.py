@@ -19,11 +19,24 @@ def fwd(i):
     call('vqa_attn_fwd', ptr(Ps[i % n_rot]), A, ptr(Vs[i % n_rot]), Dv, ptr(qa), A, ptr(wa), ptr(c), ptr(inv), ptr(p), ptr(pooled), None, Dv, B, R, A, Dv, BF16, None, 0, 0.0)
 def bwd(i):
     call('vqa_attn_bwd', ptr(Ps[i % n_rot]), A, ptr(Vs[i % n_rot]), Dv, ptr(qa), A, ptr(wa), ptr(inv), ptr(p), ptr(dpool), Dv, ptr(dP), A, ptr(dqa), ptr(dqaT), A, ptr(dwa), ptr(dc), B, R, A, Dv, BF16)
+NS = int(os.environ.get('NS', 0)) or call('vqa_attn_splits', B, R, A, Dv, BF16)
+if NS > 1:
+    wsf = torch.zeros(call('vqa_attn_split_workspace_floats', B, R, Dv, NS), device='cuda')
+    slabs = torch.zeros(NS, B, A, device='cuda'); dwa_s = torch.zeros(B * NS, A, device='cuda'); dc_s = torch.zeros(B * NS, device='cuda')
+def fwd_split(i):
+    call('vqa_attn_fwd_split', ptr(Ps[i % n_rot]), A, ptr(Vs[i % n_rot]), Dv, ptr(qa), A, ptr(wa), ptr(c), ptr(inv), ptr(p), ptr(pooled), None, Dv, B, R, A, Dv, BF16, None, 0, 0.0, NS, ptr(wsf))
+def bwd_split(i):
+    call('vqa_attn_bwd_split', ptr(Ps[i % n_rot]), A, ptr(Vs[i % n_rot]), Dv, ptr(qa), A, ptr(wa), ptr(inv), ptr(p), ptr(dpool), Dv, ptr(dP), A, ptr(slabs), A, ptr(dwa_s), ptr(dc_s), B, R, A, Dv, BF16, NS, ptr(wsf))
+    call('vqa_epilogue', ptr(slabs), NS, B * A, B, A, None, None, None, 0, 0, ptr(dqa), A, ptr(dqaT), A, BF16, 0, 0.0)
 def inv_norm(i):
     call('vqa_inv_norm', ptr(Vs[i % n_rot]), ptr(inv), B * R, Dv, Dv, BF16)
-for name, fn, nbytes in (('attn_fwd', fwd, B * (2 * R * A + 2 * R * Dv + 2 * A + 8 * R + 2 * Dv)),
-                         ('attn_bwd', bwd, B * (2 * R * Dv + 4 * R * A + 8 * R + 2 * (Dv + 2 * A))),
-                         ('inv_norm', inv_norm, B * R * (2 * Dv + 4))):
+FB, BB = B * (2 * R * A + 2 * R * Dv + 2 * A + 8 * R + 2 * Dv), B * (2 * R * Dv + 4 * R * A + 8 * R + 2 * (Dv + 2 * A))
+cases = [('attn_fwd', fwd, FB), ('attn_bwd', bwd, BB)]
+if NS > 1:
+    cases += [(f'attn_fwd_split x{NS} (+ combine launch)', fwd_split, FB), (f'attn_bwd_split x{NS} (2 launches + dqa reduce)', bwd_split, BB)]
+cases += [('inv_norm', inv_norm, B * R * (2 * Dv + 4))]
+print(f'B = {B}, R = {R}, A = {A}')
+for name, fn, nbytes in cases:
     for i in range(3): fn(i)
     torch.cuda.synchronize()
     evs = []

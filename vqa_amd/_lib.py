@@ -12,7 +12,7 @@ import os
 import torch
 
 F32, BF16 = 0, 1
-ABI_VERSION = 200          # VQA_HIP_VERSION of include/vqa_hip.h these signatures were written against
+ABI_VERSION = 210          # VQA_HIP_VERSION of include/vqa_hip.h these signatures were written against
 STATUS_WORDS = 3           # VQA_STATUS_BAD_TOKEN, VQA_STATUS_BAD_TARGET, VQA_STATUS_SKIPPED_STEP
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('VQA_HIP_LIB', os.path.join(_HERE, 'libvqa_hip.so'))   # (override: A/B of kernel builds)
@@ -52,6 +52,10 @@ _SIGNATURES = {
     'vqa_attn_bwd': [_p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _i, _p, _i, _p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _p],
     'vqa_attn_fwd_qslabs': [_p, _i, _p, _i, _p, _i, _z, _p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _u, _f, _p],
     'vqa_attn_bwd_dslabs': [_p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _i, _z, _u, _f, _p, _i, _p, _i, _p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _p],
+    'vqa_attn_splits': [_i, _i, _i, _i, _i],
+    'vqa_attn_split_workspace_floats': [_i, _i, _i, _i],
+    'vqa_attn_fwd_split': [_p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _u, _f, _i, _p, _p],
+    'vqa_attn_bwd_split': [_p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _i, _p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p],
     'vqa_gemm_splitk_hint': [_i, _i, _i, _i, _i],
     'vqa_gemm_slabs': [_p, _i, _i, _p, _i, _i, _p, _z, _i, _i, _i, _i, _i, _i, _i, _p],
     'vqa_gemm_slabs_rows': [_p, _i, _i, _p, _i, _i, _p, _z, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p],
@@ -75,9 +79,10 @@ _SIGNATURES = {
     'vqa_argmax_accuracy': [_p, _i, _i, _i, _p, _p, _i, _p, _p, _p],
     'vqa_adam_step': [_p, _p, _p, _p, _p, _l, _f, _f, _f, _f, _i, _f, _p, _p],
 }
-_RESTYPE = {'vqa_last_error_string': C.c_char_p, 'vqa_attn_lds_bytes': C.c_size_t}
+_RESTYPE = {'vqa_last_error_string': C.c_char_p, 'vqa_attn_lds_bytes': C.c_size_t,
+            'vqa_attn_split_workspace_floats': C.c_size_t}
 _NO_STATUS = {'vqa_version', 'vqa_last_error_string', 'vqa_attn_lds_bytes', 'vqa_gemm_splitk_hint',
-              'vqa_grid_mean_splits'}
+              'vqa_grid_mean_splits', 'vqa_attn_splits', 'vqa_attn_split_workspace_floats'}
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

@@ -472,6 +472,10 @@ k_attn_fwd_pipe(const bf16_t* __restrict__ P, int ldP, const bf16_t* __restrict_
 // of the published scores only), rescales its accumulators by exp(m_old - m_new), and its row group keeps a
 // partial sum of the exponentials; the groups are combined in a fixed order at the end.
 // Requirements (checked by the launcher): Dv / 8 <= 256 (at least 4 row groups), NVA <= 4.
+// Small batches (fewer samples than CUs): nsplit > 1 workgroups share a sample, each taking a contiguous range of the
+// row chunks with a running maximum of its own; it leaves the unnormalised pooled sums, its maximum and its sum of
+// exponentials in `part` ((Dv + 2) floats per workgroup) and exp(s_r - m_split) in p_out, and k_attn_fwd_combine
+// merges the ranges of a sample in a fixed order.
 template <int NVA>
 __global__ void __launch_bounds__(ATT_THREADS)
 k_attn_fwd_online(const bf16_t* __restrict__ P, int ldP, const bf16_t* __restrict__ V, int ldV,
@@ -480,7 +484,8 @@ k_attn_fwd_online(const bf16_t* __restrict__ P, int ldP, const bf16_t* __restric
                   bf16_t* __restrict__ pooled_t, float* __restrict__ pooled_f32, int ld_pool, int R, int A, int Dv,
                   bf16_t* __restrict__ pooled_drop, unsigned seed, unsigned thr, float dscale,
                   const float* __restrict__ q_slabs = nullptr, int q_nslab = 0, size_t q_stride = 0,
-                  const float* __restrict__ q_bias = nullptr, float* __restrict__ qa_out = nullptr) {
+                  const float* __restrict__ q_bias = nullptr, float* __restrict__ qa_out = nullptr,
+                  int nsplit = 1, float* __restrict__ part = nullptr) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int R4 = (R + 3) & ~3;
     float* s_s = smem;                       // scores
@@ -490,13 +495,14 @@ k_attn_fwd_online(const bf16_t* __restrict__ P, int ldP, const bf16_t* __restric
     typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
     constexpr int CH = ATT_WAVES;            // rows per chunk
 
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int b = blockIdx.x / nsplit, sp = blockIdx.x % nsplit, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const bf16_t* Pb = P + (size_t)b * R * ldP;
     const bf16_t* Vb = V + (size_t)b * R * ldV;
     const int nva = A >> 3, nv = Dv >> 3;
     const int G = ATT_THREADS / nv, grp = tid / nv, cv = tid % nv;
     const bool pool = grp < G;
-    const int nch = (R + CH - 1) / CH;
+    const int nch_all = (R + CH - 1) / CH;
+    const int k0 = nch_all * sp / nsplit, nch = nch_all * (sp + 1) / nsplit;     // this workgroup's chunks [k0, nch)
 
     int voff[NVA];
 #pragma unroll
@@ -517,8 +523,8 @@ k_attn_fwd_online(const bf16_t* __restrict__ P, int ldP, const bf16_t* __restric
     // projection arrives as partial sums, its reduction) runs under the latency of these loads
     u32x4_t pa[NVA];                                       // P row of the next chunk to score
     u32x4_t va[4];                                         // V rows of the next chunk to pool
-    load_p(0, pa);
-    load_v(0, va);
+    load_p(k0, pa);
+    load_v(k0, va);
 
     const float kk = 2.8853900817779268f;                 // 2 * log2(e)
     for (int a = tid; a < A; a += ATT_THREADS) {
@@ -575,13 +581,13 @@ k_attn_fwd_online(const bf16_t* __restrict__ P, int ldP, const bf16_t* __restric
 
     // one chunk of P rows and one chunk of V rows are always in flight (16 x 2.4 KB + 16 x 4 KB per workgroup);
     // a chunk takes several microseconds, so one chunk of look-ahead covers the HBM latency
-    score(0, pa);
-    load_p(1, pa);
+    if (k0 < nch) score(k0, pa);
+    load_p(k0 + 1, pa);
     __syncthreads();
 
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     float m = -INFINITY, l = 0.f;
-    for (int k = 0; k < nch; ++k) {
+    for (int k = k0; k < nch; ++k) {
         if (k + 1 < nch) {                                 // scores of chunk k + 1, then request chunk k + 2
             score(k + 1, pa);
             load_p(k + 2, pa);
@@ -621,6 +627,17 @@ k_attn_fwd_online(const bf16_t* __restrict__ P, int ldP, const bf16_t* __restric
     __syncthreads();
     float lt = 0.f;
     for (int g = 0; g < G; ++g) lt += l_s[g];
+    if (part) {                 // one of several row ranges of the sample: leave the pieces to k_attn_fwd_combine
+        float* pw = part + (size_t)blockIdx.x * (Dv + 2);
+        for (int i = CH * k0 + tid; i < min(CH * nch, R); i += ATT_THREADS) p_out[(size_t)b * R + i] = __expf(s_s[i] - m);
+        for (int d = tid; d < Dv; d += ATT_THREADS) {
+            float sacc = 0.f;
+            for (int g = 0; g < G; ++g) sacc += red[(size_t)g * Dv + d];
+            pw[d] = sacc;
+        }
+        if (tid == 0) { pw[Dv] = m; pw[Dv + 1] = lt; }
+        return;
+    }
     const float inv_l = 1.0f / lt;
     for (int i = tid; i < R; i += ATT_THREADS) p_out[(size_t)b * R + i] = __expf(s_s[i] - m) * inv_l;
     for (int d = tid; d < Dv; d += ATT_THREADS) {
@@ -635,9 +652,62 @@ k_attn_fwd_online(const bf16_t* __restrict__ P, int ldP, const bf16_t* __restric
     }
 }
 
+// Merge of the nsplit row ranges of a sample (one workgroup per sample, ranges in index order):
+//   m = max m_s;  L = sum_s l_s e^(m_s - m);  pooled = sum_s acc_s e^(m_s - m) / L;  p_r = p_r e^(m_s(r) - m) / L
+__global__ void __launch_bounds__(256)
+k_attn_fwd_combine(const float* __restrict__ part, int nsplit, float* __restrict__ p_out, bf16_t* __restrict__ pooled_t,
+                   float* __restrict__ pooled_f32, int ld_pool, int R, int Dv, bf16_t* __restrict__ pooled_drop,
+                   unsigned seed, unsigned thr, float dscale) {
+    constexpr int CH = ATT_WAVES, MAXS = 8;
+    __shared__ float f_s[MAXS];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* pb = part + (size_t)b * nsplit * (Dv + 2);
+    const size_t pitch = (size_t)Dv + 2;
+    // every range's (maximum, sum of exponentials) in one round trip: lane s of the first wave holds range s
+    if (tid < 64) {
+        const bool live = tid < nsplit;
+        const float ms = live ? pb[(size_t)tid * pitch + Dv] : -INFINITY;
+        const float ls = live ? pb[(size_t)tid * pitch + Dv + 1] : 0.f;
+        const float m = wave_max(ms);
+        const float e = live ? __expf(ms - m) : 0.f;
+        float L = 0.f;
+#pragma unroll
+        for (int s = 0; s < MAXS; ++s) L += __shfl(ls * e, s, 64);           // ranges in index order
+        if (tid < MAXS) f_s[tid] = e / L;
+    }
+    __syncthreads();
+    const int nch_all = (R + CH - 1) / CH;
+    for (int r = tid; r < R; r += 256) {
+        const int k = r / CH;
+        int s = 0;
+        while (s + 1 < nsplit && nch_all * (s + 1) / nsplit <= k) ++s;         // the range whose chunks hold row r
+        p_out[(size_t)b * R + r] *= f_s[s];
+    }
+    for (int d = tid; d < Dv; d += 256) {
+        float v[MAXS];
+#pragma unroll
+        for (int s = 0; s < MAXS; ++s) v[s] = pb[(size_t)min(s, nsplit - 1) * pitch + d];     // all loads in flight together
+        float sacc = 0.f;
+#pragma unroll
+        for (int s = 0; s < MAXS; ++s)
+            if (s < nsplit) sacc += v[s] * f_s[s];
+        if (pooled_f32) pooled_f32[(size_t)b * ld_pool + d] = sacc;
+        const bf16_t st = f32_to_bf16(sacc);
+        if (pooled_t) pooled_t[(size_t)b * ld_pool + d] = st;
+        if (pooled_drop)
+            pooled_drop[(size_t)b * ld_pool + d] = f32_to_bf16(bf16_to_f32(st) * drop_mult(seed, (unsigned)(b * Dv + d), thr, dscale));
+    }
+}
+
 // Backward, bf16, pipelined.  Same results layout as k_attn_bwd.  NVD = ceil(Dv / 512).
 // Phase C uses r = 1/(exp2(k (P+qa)) + 1):  t = 1 - 2r,  1 - t^2 = 4 r (1 - r).
-template <int NVD, bool NTS>
+// MODE 0: the whole backward of a sample in one workgroup.  Small batches split a sample's rows over nsplit workgroups
+// (blockIdx = b * nsplit + range) in two launches, because the softmax backward needs sum_r p_r dp_r over ALL rows:
+// MODE 1: phase A on the workgroup's rows only, dp_r stored to dp_rows (B x R);
+// MODE 2: phases B and C from dp_rows: the sum over all rows is recomputed by every workgroup (R terms), dP rows of the
+//         range are written, and the range's sums go to row blockIdx of dqa_f32 (stored [range][b][A]: split-K-style
+//         partial sums the caller reduces), dwa_part and dc_part (the caller's column sums run over all B nsplit rows).
+template <int NVD, bool NTS, int MODE = 0>
 __global__ void __launch_bounds__(ATT_THREADS)
 k_attn_bwd_pipe(const bf16_t* __restrict__ P, int ldP, const bf16_t* __restrict__ V, int ldV,
                 const float* __restrict__ qa, int ld_qa, const float* __restrict__ w_a,
@@ -646,7 +716,8 @@ k_attn_bwd_pipe(const bf16_t* __restrict__ P, int ldP, const bf16_t* __restrict_
                 float* __restrict__ dqa_f32, bf16_t* __restrict__ dqa_t, int ld_dqa, float* __restrict__ dwa_part,
                 float* __restrict__ dc_part, int R, int A, int Dv,
                 const float* __restrict__ d_slabs = nullptr, int d_nslab = 0, size_t d_stride = 0,
-                unsigned d_seed = 0, unsigned d_thr = 0, float d_scale = 1.f) {
+                unsigned d_seed = 0, unsigned d_thr = 0, float d_scale = 1.f,
+                int nsplit = 1, float* __restrict__ dp_rows = nullptr, int nbatch = 0) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* dpool_s = smem;
     float* ds_s = dpool_s + Dv;
@@ -655,27 +726,37 @@ k_attn_bwd_pipe(const bf16_t* __restrict__ P, int ldP, const bf16_t* __restrict_
     __shared__ float red2[ATT_WAVES];
     typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int b = MODE == 0 ? blockIdx.x : blockIdx.x / nsplit, sp = MODE == 0 ? 0 : blockIdx.x % nsplit;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const bf16_t* Pb = P + (size_t)b * R * ldP;
     const bf16_t* Vb = V + (size_t)b * R * ldV;
     bf16_t* dPb = dP + (size_t)b * R * ld_dP;
     const int nv = Dv >> 3, nva = A >> 3;
+    // rows of this workgroup (MODE 0: all of them)
+    const int rbeg = MODE == 0 ? 0 : (int)((long)R * sp / nsplit), rend = MODE == 0 ? R : (int)((long)R * (sp + 1) / nsplit);
+    const int orow = MODE == 2 ? sp * nbatch + b : b;        // row of the range's sums in dqa (slab layout [range][b])
+    const int prow = MODE == 2 ? blockIdx.x : b;             // ... and in dwa_part / dc_part (any order: they are summed)
 
-    for (int d = tid; d < Dv; d += ATT_THREADS) {
-        float v;
-        if (d_slabs) {          // d pooled is still in split-K partial sums (and before its dropout): reduce it here
-            v = slab_sum(d_slabs + (size_t)b * Dv + d, d_nslab, d_stride);
-            v *= drop_mult(d_seed, (unsigned)(b * Dv + d), d_thr, d_scale);
-        } else {
-            v = d_pooled[(size_t)b * ld_dpool + d];
+    if (MODE != 2) {
+        for (int d = tid; d < Dv; d += ATT_THREADS) {
+            float v;
+            if (d_slabs) {          // d pooled is still in split-K partial sums (and before its dropout): reduce it here
+                v = slab_sum(d_slabs + (size_t)b * Dv + d, d_nslab, d_stride);
+                v *= drop_mult(d_seed, (unsigned)(b * Dv + d), d_thr, d_scale);
+            } else {
+                v = d_pooled[(size_t)b * ld_dpool + d];
+            }
+            dpool_s[d] = v;
         }
-        dpool_s[d] = v;
     }
-    for (int r = tid; r < R; r += ATT_THREADS) wn_s[r] = inv_norm[(size_t)b * R + r];
+    for (int r = tid; r < R; r += ATT_THREADS) {
+        wn_s[r] = inv_norm[(size_t)b * R + r];
+        if (MODE == 2) ds_s[r] = dp_rows[(size_t)b * R + r];
+    }
     __syncthreads();
 
     // ---- phase A: dp_r = inv_norm_r * (d_pooled . V_r), one wave per row, next row in flight ----
-    {
+    if (MODE != 2) {
         float dv[NVD][8];
         int voff[NVD];
 #pragma unroll
@@ -689,11 +770,11 @@ k_attn_bwd_pipe(const bf16_t* __restrict__ P, int ldP, const bf16_t* __restrict_
         }
         u32x4_t cur[NVD], nxt[NVD];
         {
-            const bf16_t* row = Vb + (size_t)min(wv, R - 1) * ldV;
+            const bf16_t* row = Vb + (size_t)min(rbeg + wv, R - 1) * ldV;
 #pragma unroll
             for (int i = 0; i < NVD; ++i) cur[i] = __builtin_bit_cast(u32x4_t, ld_stream(row + voff[i]));
         }
-        for (int r = wv; r < R; r += ATT_WAVES) {
+        for (int r = rbeg + wv; r < rend; r += ATT_WAVES) {
             const bf16_t* rown = Vb + (size_t)min(r + ATT_WAVES, R - 1) * ldV;
 #pragma unroll
             for (int i = 0; i < NVD; ++i) nxt[i] = __builtin_bit_cast(u32x4_t, ld_stream(rown + voff[i]));
@@ -706,11 +787,15 @@ k_attn_bwd_pipe(const bf16_t* __restrict__ P, int ldP, const bf16_t* __restrict_
                     acc = fmaf(dv[i][2 * h + 1], bf16_hi(cur[i][h]), acc);
                 }
             acc = wave_sum(acc);
-            if (lane == 0) ds_s[r] = acc * wn_s[r];
+            if (lane == 0) {
+                if (MODE == 1) dp_rows[(size_t)b * R + r] = acc * wn_s[r];
+                else ds_s[r] = acc * wn_s[r];
+            }
 #pragma unroll
             for (int i = 0; i < NVD; ++i) cur[i] = nxt[i];
         }
     }
+    if (MODE == 1) return;
     __syncthreads();
 
     // phase C's geometry, and its first batch of P rows requested now: they do not depend on phase B
@@ -719,7 +804,7 @@ k_attn_bwd_pipe(const bf16_t* __restrict__ P, int ldP, const bf16_t* __restrict_
     const bf16_t* colP = Pb + (active ? cv : 0) * 8;
     u32x4_t xc[4], xn[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) xc[u] = __builtin_bit_cast(u32x4_t, ld_stream(colP + (size_t)min(min(grp, G - 1) + u * G, R - 1) * ldP));
+    for (int u = 0; u < 4; ++u) xc[u] = __builtin_bit_cast(u32x4_t, ld_stream(colP + (size_t)min(rbeg + min(grp, G - 1) + u * G, R - 1) * ldP));
 
     // ---- phase B: softmax backward -----------------------------------------------------
     float dot = 0.f;
@@ -729,10 +814,10 @@ k_attn_bwd_pipe(const bf16_t* __restrict__ P, int ldP, const bf16_t* __restrict_
     for (int r = tid; r < R; r += ATT_THREADS) {
         const float ds = p_in[(size_t)b * R + r] * (ds_s[r] - dot);
         ds_s[r] = ds;
-        dsum += ds;
+        if (r >= rbeg && r < rend) dsum += ds;
     }
     dsum = block_sum(dsum, red2);
-    if (tid == 0 && dc_part) dc_part[b] = dsum;
+    if (tid == 0 && dc_part) dc_part[prow] = dsum;
     __syncthreads();
 
     // ---- phase C: stream P, write dP, accumulate dqa / dwa; 4 rows in flight per thread ------
@@ -777,15 +862,15 @@ k_attn_bwd_pipe(const bf16_t* __restrict__ P, int ldP, const bf16_t* __restrict_
         };
         // two batches of 4 rows in flight: the next batch is requested before the current one is consumed
         // (row indices clamped, so every load is unconditional; rows past R are not consumed)
-        for (int r = grp; r < R; r += 4 * G) {
-            if (r + 4 * G < R) {
+        for (int r = rbeg + grp; r < rend; r += 4 * G) {
+            if (r + 4 * G < rend) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
                     xn[u] = __builtin_bit_cast(u32x4_t, ld_stream(colP + (size_t)min(r + (4 + u) * G, R - 1) * ldP));
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-                if (r + u * G < R) body(xc[u], r + u * G);
+                if (r + u * G < rend) body(xc[u], r + u * G);
 #pragma unroll
             for (int u = 0; u < 4; ++u) xc[u] = xn[u];
         }
@@ -799,8 +884,8 @@ k_attn_bwd_pipe(const bf16_t* __restrict__ P, int ldP, const bf16_t* __restrict_
     for (int a = tid; a < A; a += ATT_THREADS) {
         float s = 0.f;
         for (int g = 0; g < G; ++g) s += red[(size_t)g * A + a];
-        dqa_f32[(size_t)b * ld_dqa + a] = s;
-        if (dqa_t) dqa_t[(size_t)b * ld_dqa + a] = f32_to_bf16(s);
+        dqa_f32[(size_t)orow * ld_dqa + a] = s;
+        if (MODE == 0 && dqa_t) dqa_t[(size_t)b * ld_dqa + a] = f32_to_bf16(s);
     }
     __syncthreads();
     if (active) {
@@ -811,7 +896,7 @@ k_attn_bwd_pipe(const bf16_t* __restrict__ P, int ldP, const bf16_t* __restrict_
     for (int a = tid; a < A; a += ATT_THREADS) {
         float s = 0.f;
         for (int g = 0; g < G; ++g) s += red[(size_t)g * A + a];
-        dwa_part[(size_t)b * ld_dqa + a] = s;
+        dwa_part[(size_t)prow * ld_dqa + a] = s;
     }
 }
 
@@ -982,6 +1067,94 @@ static int attn_bwd_impl(const void* P, int ldP, const void* V, int ldV, const f
                                                            ld_dqa, dwa_part, dc_part, R, A, Dv);
     } else return vqa_set_error(-22, "vqa_attn_bwd: dtype");
     return vqa_check_launch("vqa_attn_bwd");
+}
+
+// ---- small batches: a sample's rows shared by nsplit workgroups ---------------------------------------------
+static bool attn_split_eligible(int R, int A, int Dv, int dtype) {
+    const int nva_l = (A / 8 + 63) / 64, nvd_l = (Dv / 8 + 63) / 64;
+    return dtype == VQA_BF16 && A % 8 == 0 && Dv % 8 == 0 && Dv / 8 <= 256 && nva_l <= 4 && A / 8 <= ATT_THREADS &&
+           nvd_l <= 4 && R <= ATT_MAX_R && ATT_ONLINE;
+}
+
+int vqa_attn_splits(int B, int R, int A, int Dv, int dtype) {
+    if (B <= 0 || R <= 0 || !attn_split_eligible(R, A, Dv, dtype)) return 1;
+    static const int n_cu = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        return n;
+    }();
+    int s = n_cu / B;                                  // one workgroup per CU: as many row ranges as fill the chip once
+    const int nch = (R + ATT_WAVES - 1) / ATT_WAVES;   // ... of at least two 16-row chunks each
+    if (s > nch / 2) s = nch / 2;
+    if (s > 8) s = 8;
+    return s < 1 ? 1 : s;
+}
+
+size_t vqa_attn_split_workspace_floats(int B, int R, int Dv, int nsplit) {
+    return (size_t)B * nsplit * (Dv + 2) + (size_t)B * R;
+}
+
+int vqa_attn_fwd_split(const void* P, int ldP, const void* V, int ldV, const float* qa, int ld_qa, const float* w_a,
+                       const float* c_a, const float* inv_norm, float* p_out, void* pooled_t, float* pooled_f32,
+                       int ld_pool, int B, int R, int A, int Dv, int dtype, void* pooled_drop, unsigned drop_seed,
+                       float drop_p, int nsplit, float* workspace, hipStream_t stream) {
+    VQA_REQUIRE(P && V && qa && w_a && c_a && inv_norm && p_out && (pooled_t || pooled_f32) && workspace, "vqa_attn_fwd_split: null pointer");
+    VQA_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "vqa_attn_fwd_split: drop_p must be in [0, 1)");
+    if (int rc = attn_check(B, R, A, Dv, ldP, ldV)) return rc;
+    VQA_REQUIRE(ld_qa >= A && ld_pool >= Dv, "vqa_attn_fwd_split: ld_qa / ld_pool too small");
+    VQA_REQUIRE(attn_split_eligible(R, A, Dv, dtype), "vqa_attn_fwd_split: shape or dtype outside the streaming bf16 kernels (vqa_attn_splits returns 1 for it)");
+    VQA_REQUIRE(nsplit >= 2 && nsplit <= 8 && nsplit <= (R + ATT_WAVES - 1) / ATT_WAVES, "vqa_attn_fwd_split: nsplit in [2, 8], at most one range per 16-row chunk");
+    if (B == 0) return 0;
+    const unsigned thr = drop_threshold(drop_p);
+    const float dsc = 1.0f / (1.0f - drop_p);
+    const size_t r4 = (size_t)((R + 3) & ~3);
+    const size_t fa = (size_t)2 * A, fc = (size_t)ATT_THREADS * 8;
+    const size_t lds_o = (2 * (r4 + 16) + (fa > fc ? fa : fc)) * sizeof(float);
+    const int nva_l = (A / 8 + 63) / 64;
+#define ATT_FWD_SPLIT(NVA)                                                                                         \
+  {                                                                                                                \
+    if (lds_o > 48 * 1024)                                                                                         \
+        if (int rc = attn_reserve_lds<k_attn_fwd_online<NVA>>("vqa_attn_fwd_split: cannot reserve LDS")) return rc; \
+    k_attn_fwd_online<NVA><<<B * nsplit, ATT_THREADS, lds_o, stream>>>((const bf16_t*)P, ldP, (const bf16_t*)V, ldV, qa, \
+        ld_qa, w_a, c_a, inv_norm, p_out, nullptr, nullptr, ld_pool, R, A, Dv, nullptr, 0u, 0u, 1.f,              \
+        nullptr, 0, 0, nullptr, nullptr, nsplit, workspace);                                                      \
+  }
+    if (nva_l == 1) ATT_FWD_SPLIT(1) else if (nva_l == 2) ATT_FWD_SPLIT(2) else if (nva_l == 3) ATT_FWD_SPLIT(3) else ATT_FWD_SPLIT(4)
+#undef ATT_FWD_SPLIT
+    k_attn_fwd_combine<<<B, 256, 0, stream>>>(workspace, nsplit, p_out, (bf16_t*)pooled_t, pooled_f32, ld_pool, R, Dv,
+                                              (bf16_t*)pooled_drop, drop_seed, thr, dsc);
+    return vqa_check_launch("vqa_attn_fwd_split");
+}
+
+int vqa_attn_bwd_split(const void* P, int ldP, const void* V, int ldV, const float* qa, int ld_qa, const float* w_a,
+                       const float* inv_norm, const float* p_in, const float* d_pooled, int ld_dpool, void* dP, int ld_dP,
+                       float* dqa_slabs, int ld_dqa, float* dwa_part, float* dc_part, int B, int R, int A, int Dv,
+                       int dtype, int nsplit, float* workspace, hipStream_t stream) {
+    VQA_REQUIRE(P && V && qa && w_a && inv_norm && p_in && d_pooled && dP && dqa_slabs && dwa_part && workspace, "vqa_attn_bwd_split: null pointer");
+    if (int rc = attn_check(B, R, A, Dv, ldP, ldV)) return rc;
+    VQA_REQUIRE(ld_qa >= A && ld_dpool >= Dv && ld_dP >= A && ld_dP % 8 == 0 && ld_dqa >= A, "vqa_attn_bwd_split: leading dimension too small");
+    VQA_REQUIRE(attn_split_eligible(R, A, Dv, dtype) && ((ld_qa & 3) == 0) && ((((uintptr_t)qa | (uintptr_t)w_a) & 15) == 0),
+                "vqa_attn_bwd_split: shape, dtype or alignment outside the streaming bf16 kernels");
+    VQA_REQUIRE(nsplit >= 2 && nsplit <= 8 && nsplit <= R, "vqa_attn_bwd_split: nsplit in [2, 8]");
+    if (B == 0) return 0;
+    const size_t r4 = (size_t)((R + 3) & ~3);
+    const size_t lds = ((size_t)Dv + 2 * r4 + (size_t)ATT_THREADS * 8) * sizeof(float);
+    const int nvd_l = (Dv / 8 + 63) / 64;
+    float* dp_rows = workspace + (size_t)B * nsplit * (Dv + 2);
+    const bool nts = (size_t)B * R * ld_dP * 2 > ((size_t)192 << 20);
+#define ATT_BWD_SPLIT_(NVD, NTS, MODE)                                                                             \
+  {                                                                                                                \
+    if (lds > 48 * 1024)                                                                                           \
+        if (int rc = attn_reserve_lds<k_attn_bwd_pipe<NVD, NTS, MODE>>("vqa_attn_bwd_split: cannot reserve LDS")) return rc; \
+    k_attn_bwd_pipe<NVD, NTS, MODE><<<B * nsplit, ATT_THREADS, lds, stream>>>((const bf16_t*)P, ldP, (const bf16_t*)V, ldV, qa, ld_qa, w_a, \
+        inv_norm, p_in, d_pooled, ld_dpool, (bf16_t*)dP, ld_dP, dqa_slabs, nullptr, ld_dqa, dwa_part, dc_part, R, A, Dv, \
+        nullptr, 0, 0, 0u, 0u, 1.f, nsplit, dp_rows, B);                                                           \
+  }
+#define ATT_BWD_SPLIT(NVD) { ATT_BWD_SPLIT_(NVD, false, 1) if (nts) ATT_BWD_SPLIT_(NVD, true, 2) else ATT_BWD_SPLIT_(NVD, false, 2) }
+    if (nvd_l == 1) ATT_BWD_SPLIT(1) else if (nvd_l == 2) ATT_BWD_SPLIT(2) else if (nvd_l == 3) ATT_BWD_SPLIT(3) else ATT_BWD_SPLIT(4)
+#undef ATT_BWD_SPLIT_
+#undef ATT_BWD_SPLIT
+    return vqa_check_launch("vqa_attn_bwd_split");
 }
 
 int vqa_attn_bwd(const void* P, int ldP, const void* V, int ldV, const float* qa, int ld_qa, const float* w_a,

@@ -853,7 +853,7 @@ class _VQAHeadModel(nn.Module):
             self._flush_wgrads()                  # (those with split K: partial sums reduced in one launch)
             self._bucket_done('linear_q.bias')
         slab, sk, st = self._gemm_slabs(ws['dzv'], F, 1, self._w('linear_v.weight'), Dv, 0, B, Dv, F)
-        if self._dpool_from_slabs and not self.train_encoder:
+        if self._dpool_from_slabs and not self.train_encoder and ws.get('attn_nsplit', 1) == 1:
             # the attention backward kernel reduces these partial sums (and applies dropoutV's mask) in its prologue;
             # nothing else touches the slab workspace before it runs
             ws['dpool_src'] = (ptr(slab), sk, st, seeds[0], p)
@@ -1177,8 +1177,14 @@ class VQAAttnModel(_VQAHeadModel):
         tdt, f32 = self.compute_dtype, torch.float32
         H, A, Dv = self.Hq, self.A, self.Dv
         ldA = self._ldA()
+        # small batches: a sample's region rows are shared by several workgroups of the attention kernels
+        ns = call('vqa_attn_splits', B, R, A, Dv, self.dt) if self.split_small_batches else 1
+        ws['attn_nsplit'] = ns
+        if ns > 1:
+            ws['attn_ws'] = z((call('vqa_attn_split_workspace_floats', B, R, Dv, ns),), f32)
+            ws['dqa_slabs'] = z((ns, B, A), f32)
         ws.update({'inv_norm': z((B * R,), f32), 'dP': z((B * R, ldA), tdt),
-                   'dqa32': z((B, A), f32), 'dqaT': z((B, A), tdt), 'dwa_part': z((B, A), f32), 'dc_part': z((B,), f32),
+                   'dqa32': z((B, A), f32), 'dqaT': z((B, A), tdt), 'dwa_part': z((B * ns, A), f32), 'dc_part': z((B * ns,), f32),
                    'du32': z((B, H), f32), 'duT': z((B, H), tdt)})
         for k in range(self.hops):
             ws[f'P{k}'] = z((B * R, ldA), tdt)
@@ -1196,6 +1202,7 @@ class VQAAttnModel(_VQAHeadModel):
     swap_big_wgrad = True    # dW_va is computed as its transpose (the faster operand orientation) and transposed by the reduce
     pad_projection_rows = True
     fuse_row_norm = True     # the first hop's projection computes the region norms itself (one pass over the features less)
+    split_small_batches = True   # fewer samples than CUs: several workgroups per sample in the attention kernels
 
     def _visual_prologue(self, ws, feats, B):
         R, Dv = feats.shape[1], self.Dv
@@ -1242,7 +1249,17 @@ class VQAAttnModel(_VQAHeadModel):
             elif not early:
                 self._linear(uT, H, pre + 'linear_qa.weight', pre + 'linear_qa.bias', B, A, H, out_pre=ws[f'qa{k}'], ld_pre=A)
             ev = self._event_pair('attn_fwd')
-            if early:               # the kernel's prologue reduces the query projection's partial sums (+ bias) into qa0
+            ns = ws['attn_nsplit']
+            if ns > 1:
+                if early:
+                    slab, sk, st = ws['early']['qa0']
+                    call('vqa_epilogue', slab, sk, st, B, A, ptr(self._f32(pre + 'linear_qa.bias')), None, None, 0, 0,
+                         ptr(ws['qa0']), A, None, 0, dt, 0, 0.0)
+                call('vqa_attn_fwd_split', ptr(ws[f'P{k}']), ldA, ptr(feats), Dv, ptr(ws[f'qa{k}']), A,
+                     ptr(self._f32(pre + 'linear_a.weight')), ptr(self._f32(pre + 'linear_a.bias')), ptr(ws['inv_norm']),
+                     ptr(ws[f'p{k}']), ptr(ws[f'pooled{k}']), None, Dv, B, R, A, Dv, dt,
+                     ptr(ws['pooled_d']) if k + 1 == self.hops else None, seed, p, ns, ptr(ws['attn_ws']))
+            elif early:             # the kernel's prologue reduces the query projection's partial sums (+ bias) into qa0
                 slab, sk, st = ws['early']['qa0']
                 call('vqa_attn_fwd_qslabs', ptr(ws[f'P{k}']), ldA, ptr(feats), Dv, slab, sk, st,
                      ptr(self._f32(pre + 'linear_qa.bias')), ptr(ws['qa0']), A,
@@ -1272,7 +1289,15 @@ class VQAAttnModel(_VQAHeadModel):
             pre = f'attention.{k}.'
             uT = ws['qT'] if k == 0 else ws[f'uT_{k}']
             src = ws.get('dpool_src') if k + 1 == self.hops else None
-            if src is not None:
+            ns = ws['attn_nsplit']
+            if ns > 1:              # row ranges: per-range sums of dqa come back as slabs, reduced (and cast) right after
+                call('vqa_attn_bwd_split', ptr(ws[f'P{k}']), ldA, ptr(feats), Dv, ptr(ws[f'qa{k}']), A,
+                     ptr(self._f32(pre + 'linear_a.weight')), ptr(ws['inv_norm']), ptr(ws[f'p{k}']), ptr(ws['d_pooled']), Dv,
+                     ptr(ws['dP']), ldA, ptr(ws['dqa_slabs']), A, ptr(ws['dwa_part']), ptr(ws['dc_part']),
+                     B, R, A, Dv, dt, ns, ptr(ws['attn_ws']))
+                call('vqa_epilogue', ptr(ws['dqa_slabs']), ns, B * A, B, A, None, None, None, 0, 0, ptr(ws['dqa32']), A,
+                     ptr(ws['dqaT']), A, dt, 0, 0.0)
+            elif src is not None:
                 slab, sk, st, dseed, dp = src
                 call('vqa_attn_bwd_dslabs', ptr(ws[f'P{k}']), ldA, ptr(feats), Dv, ptr(ws[f'qa{k}']), A,
                      ptr(self._f32(pre + 'linear_a.weight')), ptr(ws['inv_norm']), ptr(ws[f'p{k}']), slab, sk, st, dseed, dp,
@@ -1286,8 +1311,8 @@ class VQAAttnModel(_VQAHeadModel):
             # the hop's small gradients in one launch: w_a, its offset c, and the two biases that share d(P + qa);
             # the last hop's launch (the first one here) also carries the head's held weight and bias gradients
             items = [(ws['dqaT'], A, uT, H, pre + 'linear_qa.weight', A, H, B)]
-            colsums = [(ws['dwa_part'], A, B, A, _lib.F32, g(pre + 'linear_a.weight'), None),
-                       (ws['dc_part'], 1, B, 1, _lib.F32, g(pre + 'linear_a.bias'), None),
+            colsums = [(ws['dwa_part'], A, B * ns, A, _lib.F32, g(pre + 'linear_a.weight'), None),
+                       (ws['dc_part'], 1, B * ns, 1, _lib.F32, g(pre + 'linear_a.bias'), None),
                        (ws['dqa32'], A, B, A, _lib.F32, g(pre + 'linear_qa.bias'), g(pre + 'linear_va.bias'))]
             held, self._held_group = self._held_group, None
             if held is not None:
