@@ -87,7 +87,6 @@ def main():
                     help='A/B: gather embeddings and run the LSTM input projection every step instead of the per-token table')
     ap.add_argument('--no-fold-first-step', action='store_true', help='A/B: run the recurrent product of step 1 as a GEMM')
     ap.add_argument('--no-swap-wgrad', action='store_true', help='A/B: dW_va in the nn.Linear orientation')
-    ap.add_argument('--overlap-encoder', action='store_true', help='A/B: frozen question encoder on a second stream beside the region projection')
     ap.add_argument('--no-merge-head', action='store_true',
                     help="A/B: the head's weight / bias gradients in a launch of their own instead of the attention backward's")
     ap.add_argument('--no-split-attn', action='store_true', help='A/B (batch < #CUs): one attention workgroup per sample')
@@ -124,8 +123,6 @@ def main():
         model.fold_first_step = False
     if args.no_swap_wgrad:
         model.swap_big_wgrad = False
-    if args.overlap_encoder:
-        model.overlap_encoder = True
     if args.no_pad_rows:
         model.pad_projection_rows = False
     if args.no_merge_head:
@@ -266,9 +263,7 @@ def main():
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'avg_launch_ms': k6_ms, 'timed_launches': k6_n,
                          'algorithmic_bytes_per_launch': k6_bytes},
-            'roofline_gemm': dict(gemms, bound='mfma', note='HIP events on the launch stream inside the timed region'
-                                  + ('; the question encoder runs on a second stream beside the projection, so its span '
-                                     'includes the CU time the encoder kernels took' if args.overlap_encoder else '')),
+            'roofline_gemm': dict(gemms, bound='mfma', note='HIP events on the launch stream inside the timed region'),
             'loss': float(loss),
         }
         if diag:

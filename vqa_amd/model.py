@@ -694,20 +694,8 @@ class _VQAHeadModel(nn.Module):
                      seeds[li], self.seq2vec_dropout, dt)
         return ws['q32']
 
-    # frozen question encoder on a second stream beside the image side (see _forward_impl).  Off by default: the
-    # region projection holds every CU's LDS, so the encoder's kernels only run as its workgroups retire (-6 us per
-    # step same-box, and the projection's own span grows by what the encoder takes)
-    overlap_encoder = False
-
-    def _side_stream(self, device):
-        st = getattr(self, '_side', None)
-        if st is None or st.device != device:
-            self._side = st = torch.cuda.Stream(device=device)
-            self._enc_done = torch.cuda.Event()
-        return st
-
     def _visual_early(self, ws, feats, B):
-        """Question-independent part of the visual forward (runs beside the question encoder); the default is none."""
+        """Question-independent part of the visual forward, launched right after the question encoder; the default is none."""
         ws['visual_early_done'] = False
 
     def _enc_workspace(self, B, L, device):
@@ -755,27 +743,11 @@ class _VQAHeadModel(nn.Module):
         if self.train_encoder:
             self._finish_pending()               # the deferred bucket holds the encoder's own weights
             self._frozen_key = None              # they change every step: refresh the operand copies
-        # A frozen question encoder depends on nothing the image side produces (and on no trainable weight): it runs
-        # on a second stream beside the image side's question-independent work (_visual_early: the region projection
-        # of the attention model) and is joined before the first kernel that reads the question vector.  Its chain of
-        # short dependent launches fills the gaps of the one long MFMA-bound product instead of preceding it.
-        side = self._side_stream(dev) if (self.overlap_encoder and not self.train_encoder) else None
-        if side is not None:
-            main = torch.cuda.current_stream(dev)
-            self._refresh_frozen(dev)            # (allocations and table builds stay on the main stream)
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                self.encode_question(tokens, ws, seeds[4:6], q_drop=(ws['q_d'], seeds[1], p))
-                self._enc_done.record(side)
-            _lib.bind_stream()
-        else:
-            self.encode_question(tokens, ws, seeds[4:6], q_drop=(ws['q_d'], seeds[1], p))
+        self.encode_question(tokens, ws, seeds[4:6], q_drop=(ws['q_d'], seeds[1], p))
         self._visual_prologue(ws, feats, B)
         self._finish_pending()
         self._refresh_shadow()
         self._visual_early(ws, feats, B)
-        if side is not None:
-            main.wait_event(self._enc_done)
         if self.seq2vec.arch == '2-lstm':       # (the single-layer encoder's cell kernel wrote q_d already)
             call('vqa_dropout', ptr(ws['qT']), H, ptr(ws['q_d']), H, B, H, seeds[1], p, dt)
         self._launch_early(ws, B)                                  # question-side products of the head, one launch
