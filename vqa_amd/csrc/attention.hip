@@ -476,7 +476,7 @@ k_attn_fwd_pipe(const bf16_t* __restrict__ P, int ldP, const bf16_t* __restrict_
 // row chunks with a running maximum of its own; it leaves the unnormalised pooled sums, its maximum and its sum of
 // exponentials in `part` ((Dv + 2) floats per workgroup) and exp(s_r - m_split) in p_out, and k_attn_fwd_combine
 // merges the ranges of a sample in a fixed order.
-template <int NVA>
+template <int NVA, bool SPLIT = false>
 __global__ void __launch_bounds__(ATT_THREADS)
 k_attn_fwd_online(const bf16_t* __restrict__ P, int ldP, const bf16_t* __restrict__ V, int ldV,
                   const float* __restrict__ qa, int ld_qa, const float* __restrict__ w_a,
@@ -485,9 +485,10 @@ k_attn_fwd_online(const bf16_t* __restrict__ P, int ldP, const bf16_t* __restric
                   bf16_t* __restrict__ pooled_drop, unsigned seed, unsigned thr, float dscale,
                   const float* __restrict__ q_slabs = nullptr, int q_nslab = 0, size_t q_stride = 0,
                   const float* __restrict__ q_bias = nullptr, float* __restrict__ qa_out = nullptr,
-                  int nsplit = 1, float* __restrict__ part = nullptr) {
+                  int nsplit_arg = 1, float* __restrict__ part = nullptr) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int R4 = (R + 3) & ~3;
+    const int nsplit = SPLIT ? nsplit_arg : 1;            // a compile-time 1 in the one-workgroup-per-sample kernel
     float* s_s = smem;                       // scores
     float* wn_s = s_s + R4 + 16;             // inv_norm of the sample (+16: a chunk may read past R)
     float* red = wn_s + R4 + 16;             // qa / w_a staging, then the cross-group combine
@@ -495,14 +496,16 @@ k_attn_fwd_online(const bf16_t* __restrict__ P, int ldP, const bf16_t* __restric
     typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
     constexpr int CH = ATT_WAVES;            // rows per chunk
 
-    const int b = blockIdx.x / nsplit, sp = blockIdx.x % nsplit, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int b = SPLIT ? blockIdx.x / nsplit : blockIdx.x, sp = SPLIT ? blockIdx.x % nsplit : 0;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const bf16_t* Pb = P + (size_t)b * R * ldP;
     const bf16_t* Vb = V + (size_t)b * R * ldV;
     const int nva = A >> 3, nv = Dv >> 3;
     const int G = ATT_THREADS / nv, grp = tid / nv, cv = tid % nv;
     const bool pool = grp < G;
     const int nch_all = (R + CH - 1) / CH;
-    const int k0 = nch_all * sp / nsplit, nch = nch_all * (sp + 1) / nsplit;     // this workgroup's chunks [k0, nch)
+    const int k0 = SPLIT ? nch_all * sp / nsplit : 0;                             // this workgroup's chunks [k0, nch)
+    const int nch = SPLIT ? nch_all * (sp + 1) / nsplit : nch_all;
 
     int voff[NVA];
 #pragma unroll
@@ -581,7 +584,7 @@ k_attn_fwd_online(const bf16_t* __restrict__ P, int ldP, const bf16_t* __restric
 
     // one chunk of P rows and one chunk of V rows are always in flight (16 x 2.4 KB + 16 x 4 KB per workgroup);
     // a chunk takes several microseconds, so one chunk of look-ahead covers the HBM latency
-    if (k0 < nch) score(k0, pa);
+    if (!SPLIT || k0 < nch) score(k0, pa);
     load_p(k0 + 1, pa);
     __syncthreads();
 
@@ -627,7 +630,7 @@ k_attn_fwd_online(const bf16_t* __restrict__ P, int ldP, const bf16_t* __restric
     __syncthreads();
     float lt = 0.f;
     for (int g = 0; g < G; ++g) lt += l_s[g];
-    if (part) {                 // one of several row ranges of the sample: leave the pieces to k_attn_fwd_combine
+    if constexpr (SPLIT) {      // one of several row ranges of the sample: leave the pieces to k_attn_fwd_combine
         float* pw = part + (size_t)blockIdx.x * (Dv + 2);
         for (int i = CH * k0 + tid; i < min(CH * nch, R); i += ATT_THREADS) p_out[(size_t)b * R + i] = __expf(s_s[i] - m);
         for (int d = tid; d < Dv; d += ATT_THREADS) {
@@ -1114,8 +1117,8 @@ int vqa_attn_fwd_split(const void* P, int ldP, const void* V, int ldV, const flo
 #define ATT_FWD_SPLIT(NVA)                                                                                         \
   {                                                                                                                \
     if (lds_o > 48 * 1024)                                                                                         \
-        if (int rc = attn_reserve_lds<k_attn_fwd_online<NVA>>("vqa_attn_fwd_split: cannot reserve LDS")) return rc; \
-    k_attn_fwd_online<NVA><<<B * nsplit, ATT_THREADS, lds_o, stream>>>((const bf16_t*)P, ldP, (const bf16_t*)V, ldV, qa, \
+        if (int rc = attn_reserve_lds<k_attn_fwd_online<NVA, true>>("vqa_attn_fwd_split: cannot reserve LDS")) return rc; \
+    k_attn_fwd_online<NVA, true><<<B * nsplit, ATT_THREADS, lds_o, stream>>>((const bf16_t*)P, ldP, (const bf16_t*)V, ldV, qa, \
         ld_qa, w_a, c_a, inv_norm, p_out, nullptr, nullptr, ld_pool, R, A, Dv, nullptr, 0u, 0u, 1.f,              \
         nullptr, 0, 0, nullptr, nullptr, nsplit, workspace);                                                      \
   }
