@@ -50,6 +50,31 @@ for case in range(n_cases):
         errs = (rel(dP, Pd.grad * inv.double()[:, :, None]), rel(dqa, qad.grad), rel(dwa.sum(0), wad.grad))
         if errs[0] > 1e-2 or errs[1] > 1e-4 or errs[2] > 1e-4 or not torch.equal(dqa_t, dqa.to(dt)):
             print('MISMATCH bwd', tag, errs, flush=True); break
+    # the same sample's rows shared by nsplit workgroups (the small-batch form): against the one-workgroup results
+    max_ns = min(8, (R + 15) // 16, R)
+    if max_ns >= 2 and Dv // 8 <= 256 and call('vqa_attn_splits', 1, max(R, 64), A, Dv, BF16) >= 1 and (A // 8 + 63) // 64 <= 4:
+        ns = rnd.randint(2, max_ns)
+        ws = torch.full((call('vqa_attn_split_workspace_floats', B, R, Dv, ns),), float('nan'), device='cuda')
+        p2 = torch.full((B, R), -1.0, device='cuda'); pooled32_2 = torch.full((B, Dv), -1.0, device='cuda')
+        pooled_2 = torch.zeros(B, Dv, device='cuda', dtype=dt)
+        call('vqa_attn_fwd_split', ptr(P), A, ptr(V), Dv, ptr(qa), A, ptr(wa), ptr(c), ptr(inv), ptr(p2), ptr(pooled_2),
+             ptr(pooled32_2), Dv, B, R, A, Dv, BF16, None, 0, 0.0, ns, ptr(ws))
+        torch.cuda.synchronize()
+        f1 = float((p2.double() - p_ref).abs().max())
+        f2 = float((pooled32_2.double() - pooled_ref).abs().max() / pooled_ref.abs().max().clamp_min(1e-30))
+        if f1 > 2e-5 * max(1.0, float(p_ref.max()) * 10) or f2 > 2e-5 or not torch.equal(pooled_2, pooled32_2.to(dt)):
+            print('MISMATCH fwd_split', tag, ns, f1, f2, flush=True); break
+        dP2 = torch.zeros(B, R, A, device='cuda', dtype=dt)
+        slabs = torch.full((ns, B, A), float('nan'), device='cuda')
+        dwa2 = torch.full((B * ns, A), float('nan'), device='cuda'); dc2 = torch.full((B * ns,), float('nan'), device='cuda')
+        call('vqa_attn_bwd_split', ptr(P), A, ptr(V), Dv, ptr(qa), A, ptr(wa), ptr(inv), ptr(pin), ptr(dpool), Dv, ptr(dP2), A,
+             ptr(slabs), A, ptr(dwa2), ptr(dc2), B, R, A, Dv, BF16, ns, ptr(ws))
+        torch.cuda.synchronize()
+        if R > 1:
+            errs = (rel(dP2, Pd.grad * inv.double()[:, :, None]), rel(slabs.sum(0), qad.grad), rel(dwa2.sum(0), wad.grad),
+                    float((dc2.sum() - dc.sum()).abs()))
+            if errs[0] > 1e-2 or errs[1] > 1e-4 or errs[2] > 1e-4 or errs[3] > 1e-4 * max(1.0, float(dc.abs().sum())):
+                print('MISMATCH bwd_split', tag, ns, errs, flush=True); break
     if case % 20 == 0:
         print('ok', case, tag, f'{e1:.1e} {e2:.1e}', flush=True)
 else:

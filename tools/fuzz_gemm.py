@@ -14,7 +14,7 @@ for case in range(n_cases):
     N = rnd.choice([1, 8, 15, 64, 176, 255, 256, 257, 1200, 1281, rnd.randint(1, 1600)])
     K = rnd.choice([8, 64, 72, 128, 192, 320, 1000, 2048, 8 * rnd.randint(1, 300)])
     akm, bkm = rnd.choice([(1, 1), (1, 0), (0, 1), (0, 0)])
-    eng = rnd.choice([0, 4, 6, 9, 10])
+    eng = rnd.choice([0, 4, 6, 9, 10, 11])
     sk = rnd.choice([1, 1, 2, 3, 5])
     As, lda, Bs, ldb, ref = make(M, N, K, akm, bkm, torch.bfloat16, case)
     scale = float(ref.abs().max()) or 1.0
