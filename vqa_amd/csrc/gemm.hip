@@ -1042,12 +1042,18 @@ k_gemm_bf16_pp(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__
 // access to both memory and LDS, after which every wait it inserts for an LDS read becomes lgkmcnt(0) -- a full drain
 // of the prefetched fragments four times per K tile.  Written this way it counts the LDS reads exactly; the DMA is
 // waited for by hand (the counted vmcnt at Y_t).
+// (m0 holds the LDS destination of the DMA instruction.  The compiler reserves m0 and warns about the clobber; this
+//  kernel has no other user of m0 -- no LDS-DMA builtin, no indexed register access -- so nothing of the compiler's
+//  lives in it across the statement.)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
 template <bool KM>
 __device__ __forceinline__ void sp_issue_one(const bf16_t* const (&src)[2], size_t koff, unsigned quarter_lds, int wave, int ld, int which) {
     const bf16_t* p = KM ? src[which] + koff : src[0] + koff + (size_t)which * 4 * (size_t)ld;
     const unsigned dst = quarter_lds + (unsigned)((wave * 2 + which) * 1024);
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(dst), "v"(p) : "memory", "m0");
 }
+#pragma clang diagnostic pop
 
 template <bool AKM, bool BKM, bool NTS = false, bool NORM = false>
 __global__ void __launch_bounds__(512)
@@ -1194,7 +1200,7 @@ k_gemm_bf16_sp(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__
             _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                       \
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[kk][j], fa[(U) & 7], acc[i][j], 0, 0, 0); \
             if (NORM && i < 2)   /* the fragment against itself: the diagonal of the 16 x 16 result sums the squares */ \
-                gram[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[(U) & 7], fa[(U) & 7], gram[i], 0, 0, 0);  \
+                gram[i & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[(U) & 7], fa[(U) & 7], gram[i & 1], 0, 0, 0);  \
             if (PRIO) __builtin_amdgcn_s_setprio(0);                                                            \
             __builtin_amdgcn_sched_barrier(0);                                                                  \
         }
