@@ -38,8 +38,10 @@ extern "C" {
 
 /* 200: vqa_sequence_pack (+n_table_rows, status), vqa_softmax_ce (+status) and vqa_adam_step (+status) take more
  * arguments than in version 100, and vqa_gemm_slabs_group takes up to 8 products: code built against the version-100
- * header must be rebuilt (vqa_version() tells which library is loaded).  210 adds entry points only. */
-#define VQA_HIP_VERSION 210
+ * header must be rebuilt (vqa_version() tells which library is loaded).  210 adds entry points only.  220 adds
+ * vqa_lstm_resident, a fourth status word (VQA_STATUS_WORDS 3 -> 4: callers allocate the longer array) and the
+ * h_chunk_rows argument of vqa_lstm_cell01_table. */
+#define VQA_HIP_VERSION 220
 #define VQA_F32 0
 #define VQA_BF16 1
 
@@ -49,7 +51,8 @@ extern "C" {
 #define VQA_STATUS_BAD_TOKEN 0     /* a question token id outside the embedding table (nn.Embedding raises IndexError) */
 #define VQA_STATUS_BAD_TARGET 1    /* an answer id outside [0, C) (CrossEntropyLoss raises "Target out of bounds") */
 #define VQA_STATUS_SKIPPED_STEP 2  /* vqa_adam_step: the `step` of the first update it skipped because BAD_TARGET was set */
-#define VQA_STATUS_WORDS 3
+#define VQA_STATUS_RESIDENT_TIMEOUT 3 /* vqa_lstm_resident: its grid barrier did not complete; the outputs are not valid */
+#define VQA_STATUS_WORDS 4
 
 int vqa_version(void);
 const char* vqa_last_error_string(void);
@@ -119,12 +122,47 @@ int vqa_lstm_cell_packed_table(const float* slabs, int nslab, size_t slab_stride
  *  at t = 1, the one step whose recurrent input depends on a single token) */
 
 /* Steps 0 and 1 of the table form in one launch (neither needs a recurrent product once hh_table exists): the
- * outputs of vqa_lstm_cell_packed_table at t = 0 followed by t = 1 with hh_table.  L >= 2. */
+ * outputs of vqa_lstm_cell_packed_table at t = 0 followed by t = 1 with hh_table.  L >= 2.
+ * h_chunk_rows: 0, or (with H % 8 == 0) the row count of a chunk-major h, element (row, k) at
+ * ((k / 8) * h_chunk_rows + row) * 8 + k % 8 -- the layout of vqa_lstm_resident's ring (ld_h is then unused). */
 int vqa_lstm_cell01_table(const void* xg_table, int ld_xg, const float* hh_table, int n_table_rows, const int64_t* tokens,
                           float* c, void* h, int ld_h, const int32_t* lengths, float* q_f32, void* q_t, int ld_q,
                           int B, int H, int L, const int32_t* perm, const int32_t* active, const int32_t* offsets,
-                          void* hs, int ld_hs, void* q_drop, unsigned drop_seed, float drop_p, int dtype,
+                          void* hs, int ld_hs, void* q_drop, unsigned drop_seed, float drop_p, int h_chunk_rows, int dtype,
                           hipStream_t stream);
+
+/* Steps t_first .. L-1 of the table form in ONE launch, with W_hh resident in registers (no counterpart in the
+ * reference, which calls nn.LSTM, seq2vec.py:38, 43; the arithmetic is that of vqa_lstm_cell_packed_table after a
+ * recurrent product, with the four K quarters summed in a fixed order).  Workgroup g keeps the 4 x
+ * VQA_LSTM_RESIDENT_UNITS rows of W_hh (4H x H, row-major, gate order i,f,g,o, bf16) that belong to hidden units
+ * g * UNITS .., multiplies them with the live rows of h, updates its columns of the state and meets the other
+ * workgroups at a grid barrier before the next step.  bf16 storage only.
+ *   xg_table_u  (n_table_rows, H, 4) bf16: the input-projection table of vqa_lstm_cell_packed_table with the four
+ *               gates of a unit adjacent, xg_table_u[v][u][g] = xg_table[v][g * H + u]
+ *   c           (B, H) fp32, sorted row order: cell state after step t_first - 1 (read only; the state of later steps
+ *               stays on the chip)
+ *   h_ring      2 slots of (VQA_LSTM_RESIDENT_PITCH / 8, Bp, 8) bf16 with Bp = VQA_LSTM_RESIDENT_RING_ROWS(B) (B rounded
+ *               up to whole 16-row fragments plus one spare fragment), chunk-major: element (row, k) of a slot at ((k / 8) * Bp + row) * 8 + k % 8, so that the 16 rows of an
+ *               MFMA fragment are contiguous per 8-element chunk of k.  Slot 0 holds h after step t_first - 1 in sorted
+ *               row order (vqa_lstm_cell01_table with h_chunk_rows = Bp writes it); the elements with k >= H of BOTH
+ *               slots must be zero (they are never written); the slots alternate
+ *   sync_words  VQA_LSTM_RESIDENT_SYNC_WORDS 64-bit words, 128-byte aligned, zeroed by the caller ONCE (and again
+ *               after a timeout); launches that share them must not overlap
+ *   status      optional: status[VQA_STATUS_RESIDENT_TIMEOUT] = 1 if a barrier timed out (2 s), e.g. because the
+ *               workgroups could not all be resident
+ * Needs H % 8 == 0, H <= VQA_LSTM_RESIDENT_PITCH, B <= VQA_LSTM_RESIDENT_MAX_ROWS, t_first >= 1, ld_q % 4 == 0, q_f32
+ * 16-byte and q_t / q_drop 8-byte aligned, and at least
+ * vqa_lstm_resident_workgroups(H) compute units, all free to take one workgroup each. */
+#define VQA_LSTM_RESIDENT_UNITS 12
+#define VQA_LSTM_RESIDENT_PITCH 2432
+#define VQA_LSTM_RESIDENT_MAX_ROWS 512
+#define VQA_LSTM_RESIDENT_SYNC_WORDS 176
+#define VQA_LSTM_RESIDENT_RING_ROWS(B) ((((B) + 15) & ~15) + 16)
+int vqa_lstm_resident_workgroups(int H);      /* 0: H not supported */
+int vqa_lstm_resident(const void* w_hh, int ld_w, const void* xg_table_u, int n_table_rows, const int64_t* tokens,
+                      const float* c, void* h_ring, const int32_t* lengths, float* q_f32, void* q_t, int ld_q,
+                      int B, int H, int t_first, int L, const int32_t* perm, const int32_t* active, void* q_drop,
+                      unsigned drop_seed, float drop_p, uint64_t* sync_words, int32_t* status, hipStream_t stream);
 
 /* Backward through LSTM step t on packed sequences (a trainable question encoder; the reference
  * freezes it, model.py:42-43, so this has no counterpart there beyond autograd of seq2vec.py:43):

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_version_and_argument_errors_without_gpu():
     lib = _lib.load()
-    assert lib.vqa_version() == 210
+    assert lib.vqa_version() == 220
     # argument validation happens before any HIP call
     rc = lib.vqa_inv_norm(None, None, 4, 12, 12, 0, None)
     assert rc == -22 and b'vqa_inv_norm' in lib.vqa_last_error_string()

@@ -12,8 +12,15 @@ import os
 import torch
 
 F32, BF16 = 0, 1
-ABI_VERSION = 210          # VQA_HIP_VERSION of include/vqa_hip.h these signatures were written against
-STATUS_WORDS = 3           # VQA_STATUS_BAD_TOKEN, VQA_STATUS_BAD_TARGET, VQA_STATUS_SKIPPED_STEP
+ABI_VERSION = 220          # VQA_HIP_VERSION of include/vqa_hip.h these signatures were written against
+STATUS_WORDS = 4           # VQA_STATUS_BAD_TOKEN, VQA_STATUS_BAD_TARGET, VQA_STATUS_SKIPPED_STEP, VQA_STATUS_RESIDENT_TIMEOUT
+RESIDENT_PITCH, RESIDENT_MAX_ROWS, RESIDENT_SYNC_WORDS = 2432, 512, 176     # VQA_LSTM_RESIDENT_* of the header
+
+
+def resident_ring_rows(B: int) -> int:
+    """VQA_LSTM_RESIDENT_RING_ROWS(B)."""
+    return ((B + 15) & ~15) + 16
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('VQA_HIP_LIB', os.path.join(_HERE, 'libvqa_hip.so'))   # (override: A/B of kernel builds)
 
@@ -30,7 +37,9 @@ _SIGNATURES = {
     'vqa_embedding_gather_packed': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _i, _p, _i, _p],
     'vqa_lstm_cell_packed': [_p, _i, _z, _p, _i, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p, _p, _p, _u, _f, _i, _p],
     'vqa_lstm_cell_packed_table': [_p, _i, _z, _p, _i, _i, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p, _u, _f, _p, _i, _p],
-    'vqa_lstm_cell01_table': [_p, _i, _p, _i, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p, _u, _f, _i, _p],
+    'vqa_lstm_cell01_table': [_p, _i, _p, _i, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p, _u, _f, _i, _i, _p],
+    'vqa_lstm_resident_workgroups': [_i],
+    'vqa_lstm_resident': [_p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _u, _f, _p, _p, _p],
     'vqa_lstm_cell_bwd_packed': [_p, _i, _z, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     'vqa_embedding_grad': [_p, _i, _z, _i, _p, _p, _p, _i, _p, _i, _i, _i, _p],
     'vqa_colsum_multi': [_p, _i, _p],
@@ -81,7 +90,7 @@ _SIGNATURES = {
 }
 _RESTYPE = {'vqa_last_error_string': C.c_char_p, 'vqa_attn_lds_bytes': C.c_size_t,
             'vqa_attn_split_workspace_floats': C.c_size_t}
-_NO_STATUS = {'vqa_version', 'vqa_last_error_string', 'vqa_attn_lds_bytes', 'vqa_gemm_splitk_hint',
+_NO_STATUS = {'vqa_version', 'vqa_lstm_resident_workgroups', 'vqa_last_error_string', 'vqa_attn_lds_bytes', 'vqa_gemm_splitk_hint',
               'vqa_grid_mean_splits', 'vqa_attn_splits', 'vqa_attn_split_workspace_floats'}
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

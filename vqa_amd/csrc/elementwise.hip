@@ -275,7 +275,7 @@ __global__ void __launch_bounds__(256) k_lstm_cell01_table(const T* __restrict__
                             const int* __restrict__ len, float* __restrict__ q32, T* __restrict__ qT, int ld_q,
                             int H, int L, const int* __restrict__ perm, const int* __restrict__ m_t,
                             const int* __restrict__ offs, T* __restrict__ hs, int ld_hs,
-                            T* __restrict__ q_drop, unsigned seed, unsigned thr, float dscale) {
+                            T* __restrict__ q_drop, unsigned seed, unsigned thr, float dscale, int h_chunk_rows) {
     const int H4 = H >> 2;
     const int rows0 = m_t[0], rows1 = m_t[1];
     const long total = (long)rows0 * H4;
@@ -334,7 +334,10 @@ __global__ void __launch_bounds__(256) k_lstm_cell01_table(const T* __restrict__
             emit(1);
         }
         Vec4<float>::store(c + (size_t)b * H + j, cn);
-        Vec4<T>::store(h + (size_t)b * ld_h + j, hn);
+        if (h_chunk_rows > 0)      // h as [H / 8][h_chunk_rows][8]: the first ring slot of vqa_lstm_resident
+            Vec4<T>::store(h + ((size_t)(j >> 3) * h_chunk_rows + b) * 8 + (j & 7), hn);
+        else
+            Vec4<T>::store(h + (size_t)b * ld_h + j, hn);
     }
 }
 
@@ -1099,10 +1102,11 @@ int vqa_lstm_cell_packed_table(const float* slabs, int nslab, size_t slab_stride
 int vqa_lstm_cell01_table(const void* xg_table, int ld_xg, const float* hh_table, int n_table_rows, const int64_t* tokens,
                           float* c, void* h, int ld_h, const int32_t* lengths, float* q_f32, void* q_t, int ld_q,
                           int B, int H, int L, const int32_t* perm, const int32_t* active, const int32_t* offsets,
-                          void* hs, int ld_hs, void* q_drop, unsigned drop_seed, float drop_p, int dtype,
+                          void* hs, int ld_hs, void* q_drop, unsigned drop_seed, float drop_p, int h_chunk_rows, int dtype,
                           hipStream_t stream) {
     VQA_REQUIRE(xg_table && hh_table && tokens && n_table_rows > 0 && c && h && lengths && q_f32 && q_t && perm && active &&
                 offsets, "vqa_lstm_cell01_table: null pointer");
+    VQA_REQUIRE(h_chunk_rows == 0 || (h_chunk_rows >= B && H % 8 == 0), "vqa_lstm_cell01_table: h_chunk_rows is 0 or at least B, with H a multiple of 8");
     VQA_REQUIRE(B >= 0 && H > 0 && L >= 2 && ld_xg >= 4 * H && ld_h >= H && ld_q >= H, "vqa_lstm_cell01_table: bad sizes");
     VQA_REQUIRE(H % 4 == 0 && ld_xg % 4 == 0 && ld_h % 4 == 0 && ld_q % 4 == 0,
                 "vqa_lstm_cell01_table: H and leading dimensions must be multiples of 4");
@@ -1113,7 +1117,7 @@ int vqa_lstm_cell01_table(const void* xg_table, int ld_xg, const float* hh_table
     if (B == 0) return 0;
     DISPATCH_T(dtype, (k_lstm_cell01_table<T><<<grid_for((long)B * (H / 4), 256), 256, 0, stream>>>(
         (const T*)xg_table, ld_xg, hh_table, n_table_rows, tokens, c, (T*)h, ld_h, lengths, q_f32, (T*)q_t, ld_q, H, L,
-        perm, active, offsets, (T*)hs, ld_hs, (T*)q_drop, drop_seed, thr, dsc)));
+        perm, active, offsets, (T*)hs, ld_hs, (T*)q_drop, drop_seed, thr, dsc, h_chunk_rows)));
     return vqa_check_launch("vqa_lstm_cell01_table");
 }
 

@@ -199,6 +199,8 @@ class _VQAHeadModel(nn.Module):
         self.fold_first_step = True   # ... and the first recurrent product (h_0 depends on one token)
         self.fuse_first_two_cells = True   # steps 0 and 1 then run as one launch
         self.fold_embedding = True    # frozen encoder: embedding x first input projection tabulated per token id
+        self.resident_encoder = True  # ... and steps 2.. of a single bf16 layer in one launch, W_hh resident in registers
+        self._xg_table_u = self._resident_sync = None
         self.grad_ready_hook = None   # callable(bucket_index) fired as gradient buckets complete
         self.kernel_events = None     # set to {} to collect per-kernel HIP event pairs
         self.kernel_event_stride = 1  # time every n-th launch only (an event pair costs the stream ~10 us of gaps)
@@ -335,7 +337,7 @@ class _VQAHeadModel(nn.Module):
             ps += [rnn.weight_ih_l0, rnn.weight_hh_l0, rnn.bias_ih_l0, rnn.bias_hh_l0]
         if self.Ec:
             ps.append(self.caption_embedding.weight)
-        key = tuple((p.data_ptr(), p._version) for p in ps) + (str(device), self.fold_embedding, self.fold_first_step, self.train_encoder)
+        key = tuple((p.data_ptr(), p._version) for p in ps) + (str(device), self.fold_embedding, self.fold_first_step, self.train_encoder, self.resident_encoder)
         if key == self._frozen_key:
             return
         tdt = self.compute_dtype
@@ -357,7 +359,7 @@ class _VQAHeadModel(nn.Module):
         # Frozen encoder: embedding followed by the first layer's input projection is one fixed map per token id, so
         # it is tabulated here, once per weight version: xg_table[v] = act(emb[v]) W_ih^T + b_ih + b_hh, computed by
         # the same GEMM kernel on the same rows as the per-step projection it replaces (bit-identical values).
-        self._xg_table = self._hh_table = None
+        self._xg_table = self._hh_table = self._xg_table_u = self._resident_sync = None
         V1, H4 = self._emb_t.shape[0], 4 * self.seq2vec.layers[0].hidden_size
         if self.fold_embedding and not self.train_encoder and V1 * H4 * self._emb_t.element_size() <= (1 << 30):
             wih, _, bias = self._enc_layers[0]
@@ -392,6 +394,14 @@ class _VQAHeadModel(nn.Module):
                 call('vqa_gemm_fused', ptr(h0), Hh, 1, ptr(whh), Hh, 1, ptr(hh), H4, V1, H4, Hh, None, None, 0,
                      _lib.F32, self.dt, self.gemm_engine)
                 self._hh_table = hh
+                # All later steps in one launch with W_hh resident in registers (vqa_lstm_resident): single layer,
+                # bf16, as many free compute units as the layer has groups of 12 hidden units.  Its table has the four
+                # gates of a unit adjacent (one 8-byte gather per cell).
+                nwg = call('vqa_lstm_resident_workgroups', Hh)
+                if (self.resident_encoder and self.dt == _lib.BF16 and len(self._enc_layers) == 1 and nwg > 0 and
+                        nwg <= torch.cuda.get_device_properties(device).multi_processor_count):
+                    self._xg_table_u = table.view(V1, 4, Hh).transpose(1, 2).contiguous()
+                    self._resident_sync = torch.zeros(_lib.RESIDENT_SYNC_WORDS, dtype=torch.int64, device=device)
         self._frozen_key = key
 
     # ------------------------------------------------------------------ workspace
@@ -659,12 +669,21 @@ class _VQAHeadModel(nn.Module):
             qT = ws['qT'].data_ptr() + esz * li * Hh
             t_first = 0
             if from_table and self._hh_table is not None and L >= 2 and self.fuse_first_two_cells:   # no GEMM between them
+                resident = (self._xg_table_u is not None and hs is None and L > 2 and B <= _lib.RESIDENT_MAX_ROWS)
+                if resident and 'h_ring' not in ws:      # two slots of h, chunk-major, K padded with zeros to the kernel's contraction length
+                    ws['h_ring'] = torch.zeros((2, _lib.RESIDENT_PITCH // 8, _lib.resident_ring_rows(B), 8), dtype=self.compute_dtype, device=dev)
                 call('vqa_lstm_cell01_table', ptr(table), 4 * Hh, ptr(self._hh_table), table.shape[0], ptr(tokens),
-                     ptr(ws['c']), ptr(ws['h']), Hh, ptr(ws['len']), q32, qT, Hq, B, Hh, L, ptr(ws['perm']),
-                     ptr(ws['m_t']), ptr(ws['offs']), ptr(hs), Hh,
+                     ptr(ws['c']), ptr(ws['h_ring'] if resident else ws['h']), Hh, ptr(ws['len']), q32, qT, Hq, B, Hh, L,
+                     ptr(ws['perm']), ptr(ws['m_t']), ptr(ws['offs']), ptr(hs), Hh,
                      ptr(q_drop[0]) if fuse_drop else None, q_drop[1] if fuse_drop else 0,
-                     q_drop[2] if fuse_drop else 0.0, dt)
+                     q_drop[2] if fuse_drop else 0.0, _lib.resident_ring_rows(B) if resident else 0, dt)
                 t_first = 2
+                if resident:                             # steps 2 .. L-1 in one launch, W_hh resident in registers
+                    call('vqa_lstm_resident', ptr(whh), Hh, ptr(self._xg_table_u), table.shape[0], ptr(tokens),
+                         ptr(ws['c']), ptr(ws['h_ring']), ptr(ws['len']), q32, qT, Hq, B, Hh, 2, L, ptr(ws['perm']),
+                         ptr(ws['m_t']), ptr(q_drop[0]) if fuse_drop else None, q_drop[1] if fuse_drop else 0,
+                         q_drop[2] if fuse_drop else 0.0, ptr(self._resident_sync), ptr(self._status_words(dev)))
+                    t_first = L
             h_cur = ws['h']
             for t in range(t_first, L):
                 hh_tab = self._hh_table if (from_table and t == 1) else None     # step 1's recurrent product, tabulated
@@ -979,7 +998,14 @@ class _VQAHeadModel(nn.Module):
         st = getattr(self, '_status', None)
         if st is None:
             return
-        tok, tgt, skipped = st.tolist()
+        tok, tgt, skipped, resident_timeout = st.tolist()
+        if resident_timeout:
+            st.zero_()
+            if self._resident_sync is not None:
+                self._resident_sync.zero_()
+            raise _lib.VqaHipError('vqa_lstm_resident: its grid barrier timed out (the workgroups were not all resident: is '
+                              'another process using the GPU?); the question vectors of that step are not valid -- '
+                              'construct the module with resident_encoder=False to use the per-step kernels')
         if tok or tgt:
             st.zero_()
             if skipped:
