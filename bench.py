@@ -87,6 +87,8 @@ def main():
     ap.add_argument('--no-fold-embedding', action='store_true',
                     help='A/B: gather embeddings and run the LSTM input projection every step instead of the per-token table')
     ap.add_argument('--no-fold-first-step', action='store_true', help='A/B: run the recurrent product of step 1 as a GEMM')
+    ap.add_argument('--no-resident-encoder', action='store_true',
+                    help='A/B: one recurrent GEMM + one cell launch per step instead of the weight-stationary launch')
     ap.add_argument('--no-swap-wgrad', action='store_true', help='A/B: dW_va in the nn.Linear orientation')
     ap.add_argument('--no-merge-head', action='store_true',
                     help="A/B: the head's weight / bias gradients in a launch of their own instead of the attention backward's")
@@ -104,6 +106,9 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', '0'))
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
+    if world > 1 or args.rccl_single:
+        from vqa_amd.parallel import reserve_compute_units_for_resident_kernels
+        reserve_compute_units_for_resident_kernels()
     if world > 1:
         dist.init_process_group('nccl', device_id=dev)
     elif args.rccl_single:
@@ -120,6 +125,8 @@ def main():
         model.fuse_row_norm = False
     if args.no_fold_embedding:
         model.fold_embedding = False
+    if args.no_resident_encoder:
+        model.resident_encoder = False
     if args.no_fold_first_step:
         model.fold_first_step = False
     if args.no_swap_wgrad:
@@ -295,7 +302,9 @@ def main():
                                            + ('tabulated per token id when the weights are loaded' if model.fold_embedding
                                               else 'computed every step')
                                            + ('; step 1 recurrent product tabulated too' if model.fold_embedding
-                                              and model.fold_first_step else '')},
+                                              and model.fold_first_step else '')
+                                           + ('; steps 2.. in one launch with W_hh resident in registers'
+                                              if getattr(model, '_xg_table_u', None) is not None else '')},
             'roofline': {'bound': 'hbm', 'kernel': 'k_attn_fwd_online (fused attention forward)', 'achieved': achieved,
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'avg_launch_ms': k6_ms, 'timed_launches': k6_n,

@@ -98,3 +98,21 @@ def test_resident_entry_point_rejects_what_it_cannot_run():
     for bad in (args(2440, 8, 2, 5), args(48, 600, 2, 5), args(48, 8, 0, 5), args(44, 8, 2, 5)):
         assert lib.vqa_lstm_resident(*bad) == -22
         assert b'vqa_lstm_resident' in lib.vqa_last_error_string()
+
+
+def test_resident_barrier_abort_raises_and_recovers():
+    """A barrier that cannot complete (here: the abort word is set before the launch) makes every workgroup leave, sets
+    the status word, and the module raises at its next check, clears the barrier words and works again."""
+    from vqa_amd import _lib
+    m, _ = _model(104)
+    tok = _tokens(40, 9, 60, seed=4)
+    q_good, _, _, used = _encode(m, tok, True)
+    assert used
+    m._resident_sync[16 * 8] = 1                     # the abort word: one 128-byte line per word, ninth line
+    m.resident_encoder = True
+    m.encode_question(tok.cuda())
+    with pytest.raises(_lib.VqaHipError, match='grid barrier'):
+        m.check_status()
+    assert int(m._resident_sync.abs().sum()) == 0
+    q_again, _, _, _ = _encode(m, tok, True)
+    assert torch.equal(q_again, q_good)

@@ -26,20 +26,22 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned long long u64;
 
+#ifndef RES_NH
 #define RES_NH VQA_LSTM_RESIDENT_UNITS        // hidden units per workgroup
+#endif
 #define RES_KSUB 19                           // 32-deep K sub-steps per wave
 #define RES_PITCH VQA_LSTM_RESIDENT_PITCH     // 4 waves x 19 x 32: the padded contraction length
 #ifndef RES_RF
 #define RES_RF 4                              // 16-row fragments of h per pass (64 batch rows; 128-row passes with 3 buffers: +2 %)
 #endif
-#define RES_NJ 3                              // 16-row fragments of the W slice (48 gate rows)
+#define RES_NJ (RES_NH / 4)                   // 16-row fragments of the W slice (4 gate rows per hidden unit)
 #ifndef RES_NBUF
 #define RES_NBUF 6                            // fragment buffers per wave: sub-steps s .. s + 5 requested or in use
 #endif
 #define RES_CELLS (RES_RF * RES_NJ / 4)       // (fragment, W fragment) pairs a wave updates per pass
 
 static_assert(RES_NH * 4 == RES_NJ * 16, "a workgroup's gate rows are whole MFMA fragments");
-static_assert(RES_RF * RES_NJ % 4 == 0 && (RES_RF == 4 || RES_RF == 8), "the pass's cells split evenly over the four waves");
+static_assert(RES_RF * RES_NJ % 4 == 0 && RES_RF <= 8, "the pass's cells split evenly over the four waves");
 static_assert(RES_PITCH == 4 * RES_KSUB * 32, "the ring pitch is the padded contraction length");
 
 // synchronisation words (u64 each, one 128-byte line per word): eight arrival counters (workgroup g counts into
@@ -212,7 +214,17 @@ k_lstm_resident(const bf16_t* __restrict__ whh, int ldw, const bf16_t* __restric
         __syncthreads();
 
         const int nfrag = (rows + 15) >> 4;
-        for (int f0 = 0; f0 < nfrag; f0 += RES_RF) {
+        // The workgroups of an XCD (blockIdx.x % 8 under round-robin placement) start at different passes and wrap:
+        // at any moment they read different rows of h, so most of a workgroup's lines were already brought into the
+        // XCD's L2 by a neighbour instead of every workgroup waiting on the same miss.
+        const int npass = (nfrag + RES_RF - 1) / RES_RF;
+#ifdef RES_NO_ROTATE
+        const int rot = 0;
+#else
+        const int rot = (blockIdx.x >> 3) % npass;
+#endif
+        for (int ps = 0; ps < npass; ++ps) {
+            const int f0 = ((ps + rot) % npass) * RES_RF;
             const int nf = min(RES_RF, nfrag - f0);
             // this wave's cells of the pass: (fragment i, W fragment j) pairs p = RES_CELLS wave ...  The unit's four
             // gates are adjacent in the table: one 8-byte load per cell, in flight under the MFMAs (always issued, from a
@@ -241,13 +253,15 @@ k_lstm_resident(const bf16_t* __restrict__ whh, int ldw, const bf16_t* __restric
                 case 8: case 7: product_pass<8>(wf, hp0, sub_stride, acc); break;     // (fragments past the batch: the
                 case 6: case 5: product_pass<6>(wf, hp0, sub_stride, acc); break;     //  ring has 16 spare rows per chunk)
 #endif
+#if RES_RF >= 4
                 case 4: product_pass<4>(wf, hp0, sub_stride, acc); break;
+#endif
                 case 3: product_pass<3>(wf, hp0, sub_stride, acc); break;
                 case 2: product_pass<2>(wf, hp0, sub_stride, acc); break;
                 default: product_pass<1>(wf, hp0, sub_stride, acc); break;
             }
 
-            RES_STAMP(t - t_first, 2 + 2 * (f0 / RES_RF));
+            RES_STAMP(t - t_first, 2 + 2 * ps);
             // the four K quarters meet in LDS
 #pragma unroll
             for (int i = 0; i < RES_RF; ++i)
@@ -276,7 +290,7 @@ k_lstm_resident(const bf16_t* __restrict__ whh, int ldw, const bf16_t* __restric
                 hst[o] = og * fast_tanh(cn);
             }
             LDS_BARRIER();                    // red may be rewritten by the next pass
-            RES_STAMP(t - t_first, 3 + 2 * (f0 / RES_RF));
+            RES_STAMP(t - t_first, 3 + 2 * ps);
         }
         // The step's h leaves after the last pass (a store between the passes would sit in the same in-order counter
         // as the next pass's loads): four units of one row per 8-byte write-through store, which needs no L2

@@ -20,6 +20,16 @@ import torch
 import torch.distributed as dist
 
 
+def reserve_compute_units_for_resident_kernels(max_channels: int = 48) -> None:
+    """Call BEFORE ``init_process_group``.  The question encoder's weight-stationary kernel (vqa_lstm_resident) needs
+    200 of the 256 compute units to itself for the length of its launch -- each of its workgroups takes a whole CU's
+    registers and all of them meet at grid barriers -- and it runs while the previous step's gradient all-reduce is
+    still in flight.  An RCCL kernel occupies one CU per channel, so the channel count is capped (unless the user set
+    NCCL_MAX_NCHANNELS) to keep 200 CUs free; beyond the cap the encoder would simply start after the collective."""
+    import os
+    os.environ.setdefault('NCCL_MAX_NCHANNELS', str(int(max_channels)))
+
+
 class GradReducer:
     def __init__(self, process_group: Optional["dist.ProcessGroup"] = None, defer_last: bool = True,
                  force: bool = False, bucket_bytes: int = 32 << 20, defer_all: bool = True):

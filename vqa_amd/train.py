@@ -247,6 +247,8 @@ def init_distributed(args):
     torch.cuda.set_device(dev)
     started = launched and not _dist_on()
     if started:
+        from .parallel import reserve_compute_units_for_resident_kernels
+        reserve_compute_units_for_resident_kernels()
         dist.init_process_group('nccl', device_id=dev)
     return rank, world, dev, started
 
