@@ -116,3 +116,27 @@ def test_resident_barrier_abort_raises_and_recovers():
     assert int(m._resident_sync.abs().sum()) == 0
     q_again, _, _, _ = _encode(m, tok, True)
     assert torch.equal(q_again, q_good)
+
+
+def test_resident_handoff_is_repeatable_under_load():
+    """The hidden state crosses the chip once per step through global memory (write-through stores, arrival counters,
+    one acquire).  A stale read would depend on timing: 150 launches on the same questions must give the same bits,
+    idle and beside a second stream that keeps HBM, the L2s and some compute units busy."""
+    m, _ = _model(2400, E=620, vq=300)
+    tok = _tokens(256, 14, 300, seed=21).cuda()
+    m.resident_encoder = True
+    first = m.encode_question(tok).clone()
+    assert m._xg_table_u is not None
+    big = torch.empty(64 << 20, dtype=torch.float32, device='cuda')       # 256 MiB: larger than the L2s together
+    side = torch.cuda.Stream()
+    stop = 150
+    for load in (False, True):
+        for i in range(stop):
+            if load:
+                with torch.cuda.stream(side):
+                    big.add_(1.0)
+            q = m.encode_question(tok)
+            if i % 10 == 9 or i == stop - 1:
+                assert torch.equal(q, first), (load, i)
+    torch.cuda.synchronize()
+    m.check_status()
