@@ -148,7 +148,7 @@ int vqa_lstm_cell01_table(const void* xg_table, int ld_xg, const float* hh_table
  *               slots must be zero (they are never written); the slots alternate
  *   sync_words  VQA_LSTM_RESIDENT_SYNC_WORDS 64-bit words, 128-byte aligned, zeroed by the caller ONCE (and again
  *               after a timeout); launches that share them must not overlap
- *   status      optional: status[VQA_STATUS_RESIDENT_TIMEOUT] = 1 if a barrier timed out (2 s), e.g. because the
+ *   status      optional: status[VQA_STATUS_RESIDENT_TIMEOUT] = 1 if a barrier timed out (10 s), e.g. because the
  *               workgroups could not all be resident
  * Needs H % 8 == 0, H <= VQA_LSTM_RESIDENT_PITCH, B <= VQA_LSTM_RESIDENT_MAX_ROWS, t_first >= 1, ld_q % 4 == 0, q_f32
  * 16-byte and q_t / q_drop 8-byte aligned, and at least

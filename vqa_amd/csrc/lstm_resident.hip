@@ -83,7 +83,7 @@ __device__ __forceinline__ bool grid_barrier(u64* sync, u64 epoch, int nwg, int*
         for (;;) {
             const u64 v = lane <= 8 ? __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
             if (__all(lane >= 8 || v >= want)) break;
-            if (__any(lane == 8 && v != 0) || wall_clock64() - t0 > 200000000ull) {     // 2 s of the 100 MHz clock
+            if (__any(lane == 8 && v != 0) || wall_clock64() - t0 > 1000000000ull) {    // 10 s of the 100 MHz clock
                 if (lane == 0) __hip_atomic_store(sync + SYNC_ABORT, (u64)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 good = 0;
                 break;
