@@ -38,10 +38,10 @@ typedef unsigned long long u64;
 #ifndef RES_NBUF
 #define RES_NBUF 6                            // fragment buffers per wave: sub-steps s .. s + 5 requested or in use
 #endif
-#define RES_CELLS (RES_RF * RES_NJ / 4)       // (fragment, W fragment) pairs a wave updates per pass
+#define RES_CELLS ((RES_RF * RES_NJ + 3) / 4) // (fragment, W fragment) pairs a wave updates per pass (the last wave may have fewer)
 
 static_assert(RES_NH * 4 == RES_NJ * 16, "a workgroup's gate rows are whole MFMA fragments");
-static_assert(RES_RF * RES_NJ % 4 == 0 && RES_RF <= 8, "the pass's cells split evenly over the four waves");
+static_assert(RES_RF >= 3 && RES_RF <= 8, "fragment counts the pass switch below knows");
 static_assert(RES_PITCH == 4 * RES_KSUB * 32, "the ring pitch is the padded contraction length");
 
 // synchronisation words (u64 each, one 128-byte line per word): eight arrival counters (workgroup g counts into
@@ -238,7 +238,7 @@ k_lstm_resident(const bf16_t* __restrict__ whh, int ldw, const bf16_t* __restric
                 const int p = wave * RES_CELLS + q, i = p / RES_NJ, j = p - RES_NJ * i;
                 crow[q] = (f0 + i) * 16 + (lane & 15);
                 cu[q] = 4 * j + (lane >> 4);
-                clive[q] = i < nf && crow[q] < rows && unit0 + cu[q] < H;
+                clive[q] = p < RES_RF * RES_NJ && i < nf && crow[q] < rows && unit0 + cu[q] < H;
                 xgv[q] = *reinterpret_cast<const u32x2*>(xgu + ((size_t)id_l[min(crow[q], rows - 1)] * H + min(unit0 + cu[q], H - 1)) * 4);
             }
 
@@ -249,9 +249,17 @@ k_lstm_resident(const bf16_t* __restrict__ whh, int ldw, const bf16_t* __restric
                 for (int j = 0; j < RES_NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
             const bf16_t* hp0 = hin + ((size_t)kc0 * Bp + f0 * 16 + (lane & 15)) * 8;
             switch (nf) {                      // rows past the live ones of the last fragment are stale, never used
-#if RES_RF == 8
-                case 8: case 7: product_pass<8>(wf, hp0, sub_stride, acc); break;     // (fragments past the batch: the
-                case 6: case 5: product_pass<6>(wf, hp0, sub_stride, acc); break;     //  ring has 16 spare rows per chunk)
+#if RES_RF >= 8
+                case 8: product_pass<8>(wf, hp0, sub_stride, acc); break;
+#endif
+#if RES_RF >= 7
+                case 7: product_pass<7>(wf, hp0, sub_stride, acc); break;
+#endif
+#if RES_RF >= 6
+                case 6: product_pass<6>(wf, hp0, sub_stride, acc); break;
+#endif
+#if RES_RF >= 5
+                case 5: product_pass<5>(wf, hp0, sub_stride, acc); break;
 #endif
 #if RES_RF >= 4
                 case 4: product_pass<4>(wf, hp0, sub_stride, acc); break;
