@@ -87,6 +87,8 @@ def main():
     ap.add_argument('--no-fold-embedding', action='store_true',
                     help='A/B: gather embeddings and run the LSTM input projection every step instead of the per-token table')
     ap.add_argument('--no-fold-first-step', action='store_true', help='A/B: run the recurrent product of step 1 as a GEMM')
+    ap.add_argument('--no-resident-whole', action='store_true',
+                    help='A/B: sequence packing and the two tabulated steps as launches of their own before the resident launch')
     ap.add_argument('--no-resident-encoder', action='store_true',
                     help='A/B: one recurrent GEMM + one cell launch per step instead of the weight-stationary launch')
     ap.add_argument('--no-swap-wgrad', action='store_true', help='A/B: dW_va in the nn.Linear orientation')
@@ -127,6 +129,8 @@ def main():
         model.fold_embedding = False
     if args.no_resident_encoder:
         model.resident_encoder = False
+    if args.no_resident_whole:
+        model.resident_whole = False
     if args.no_fold_first_step:
         model.fold_first_step = False
     if args.no_swap_wgrad:

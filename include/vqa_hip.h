@@ -137,31 +137,40 @@ int vqa_lstm_cell01_table(const void* xg_table, int ld_xg, const float* hh_table
  * VQA_LSTM_RESIDENT_UNITS rows of W_hh (4H x H, row-major, gate order i,f,g,o, bf16) that belong to hidden units
  * g * UNITS .., multiplies them with the live rows of h, updates its columns of the state and meets the other
  * workgroups at a grid barrier before the next step.  bf16 storage only.
+ *   t_first = 0 the WHOLE encoder in this launch: every workgroup packs the sequences for itself (the arithmetic of
+ *               vqa_sequence_pack: seq2vec.py:11-14, 16-25; a token id outside the table sets
+ *               status[VQA_STATUS_BAD_TOKEN]) and runs steps 0 and 1 of its units from the two tables (the arithmetic
+ *               of vqa_lstm_cell01_table); needs hh_table and L >= 2; c is not read; lengths / perm / active are
+ *               optional OUTPUTS (what vqa_sequence_pack would have written; offsets are not produced)
+ *   t_first >= 1 the caller ran vqa_sequence_pack and the steps before t_first: lengths, perm, active and c are inputs
  *   xg_table_u  (n_table_rows, H, 4) bf16: the input-projection table of vqa_lstm_cell_packed_table with the four
  *               gates of a unit adjacent, xg_table_u[v][u][g] = xg_table[v][g * H + u]
+ *   hh_table    (n_table_rows, 4H) fp32, as vqa_lstm_cell_packed_table's (t_first = 0 only)
  *   c           (B, H) fp32, sorted row order: cell state after step t_first - 1 (read only; the state of later steps
  *               stays on the chip)
  *   h_ring      2 slots of (VQA_LSTM_RESIDENT_PITCH / 8, Bp, 8) bf16 with Bp = VQA_LSTM_RESIDENT_RING_ROWS(B) (B rounded
- *               up to whole 16-row fragments plus one spare fragment), chunk-major: element (row, k) of a slot at ((k / 8) * Bp + row) * 8 + k % 8, so that the 16 rows of an
- *               MFMA fragment are contiguous per 8-element chunk of k.  Slot 0 holds h after step t_first - 1 in sorted
- *               row order (vqa_lstm_cell01_table with h_chunk_rows = Bp writes it); the elements with k >= H of BOTH
- *               slots must be zero (they are never written); the slots alternate
+ *               up to whole 16-row fragments plus one spare fragment), chunk-major: element (row, k) of a slot at
+ *               ((k / 8) * Bp + row) * 8 + k % 8, so that the 16 rows of an MFMA fragment are contiguous per 8-element
+ *               chunk of k.  With t_first >= 1 slot 0 holds h after step t_first - 1 in sorted row order
+ *               (vqa_lstm_cell01_table with h_chunk_rows = Bp writes it); the elements with k >= H of BOTH slots
+ *               must be zero (they are never written); the slots alternate
  *   sync_words  VQA_LSTM_RESIDENT_SYNC_WORDS 64-bit words, 128-byte aligned, zeroed by the caller ONCE (and again
  *               after a timeout); launches that share them must not overlap
  *   status      optional: status[VQA_STATUS_RESIDENT_TIMEOUT] = 1 if a barrier timed out (10 s), e.g. because the
  *               workgroups could not all be resident
- * Needs H % 8 == 0, H <= VQA_LSTM_RESIDENT_PITCH, B <= VQA_LSTM_RESIDENT_MAX_ROWS, t_first >= 1, ld_q % 4 == 0, q_f32
- * 16-byte and q_t / q_drop 8-byte aligned, and at least
+ * Needs H % 8 == 0, H <= VQA_LSTM_RESIDENT_PITCH, B <= VQA_LSTM_RESIDENT_MAX_ROWS, L <= VQA_LSTM_RESIDENT_MAX_STEPS,
+ * ld_q % 4 == 0, q_f32 / tables 16-byte and q_t / q_drop 8-byte aligned, and at least
  * vqa_lstm_resident_workgroups(H) compute units, all free to take one workgroup each. */
 #define VQA_LSTM_RESIDENT_UNITS 12
 #define VQA_LSTM_RESIDENT_PITCH 2432
 #define VQA_LSTM_RESIDENT_MAX_ROWS 512
+#define VQA_LSTM_RESIDENT_MAX_STEPS 64
 #define VQA_LSTM_RESIDENT_SYNC_WORDS 176
 #define VQA_LSTM_RESIDENT_RING_ROWS(B) ((((B) + 15) & ~15) + 16)
 int vqa_lstm_resident_workgroups(int H);      /* 0: H not supported */
-int vqa_lstm_resident(const void* w_hh, int ld_w, const void* xg_table_u, int n_table_rows, const int64_t* tokens,
-                      const float* c, void* h_ring, const int32_t* lengths, float* q_f32, void* q_t, int ld_q,
-                      int B, int H, int t_first, int L, const int32_t* perm, const int32_t* active, void* q_drop,
+int vqa_lstm_resident(const void* w_hh, int ld_w, const void* xg_table_u, const float* hh_table, int n_table_rows,
+                      const int64_t* tokens, const float* c, void* h_ring, int32_t* lengths, float* q_f32, void* q_t, int ld_q,
+                      int B, int H, int t_first, int L, int32_t* perm, int32_t* active, void* q_drop,
                       unsigned drop_seed, float drop_p, uint64_t* sync_words, int32_t* status, hipStream_t stream);
 
 /* Backward through LSTM step t on packed sequences (a trainable question encoder; the reference

@@ -32,8 +32,9 @@ def _tokens(B, L, vq, seed, full=False):
     return tok
 
 
-def _encode(m, tok, resident, drop=None):
+def _encode(m, tok, resident, drop=None, whole=True):
     m.resident_encoder = resident
+    m.resident_whole = whole       # True: packing and the two tabulated steps run inside the same launch
     B = tok.shape[0]
     qd = None
     if drop is not None:
@@ -46,14 +47,21 @@ def _encode(m, tok, resident, drop=None):
     return q, qt, qd, used
 
 
+@pytest.mark.parametrize('whole', [True, False])
 @pytest.mark.parametrize('B,H,L', [(5, 48, 7), (70, 104, 14), (64, 16, 3), (300, 200, 9), (512, 72, 5)])
-def test_resident_steps_match_per_step_kernels_and_oracle(B, H, L):
+def test_resident_steps_match_per_step_kernels_and_oracle(B, H, L, whole):
     m, po = _model(H)
     tok = _tokens(B, L, 60, seed=B + H + L)
-    q_res, qt_res, qd_res, used = _encode(m, tok, True, drop=(1234, 0.5))
+    q_res, qt_res, qd_res, used = _encode(m, tok, True, drop=(1234, 0.5), whole=whole)
+    if whole:        # what vqa_sequence_pack would have left in the workspace
+        ws = m._enc_workspace(B, L, torch.device('cuda', torch.cuda.current_device()))
+        packed = {k: ws[k].clone() for k in ('len', 'perm', 'm_t')}
     assert used, 'the resident kernel was not selected'
     q_ref, qt_ref, qd_ref, used_ref = _encode(m, tok, False, drop=(1234, 0.5))
     assert not used_ref
+    if whole:
+        for k, v in packed.items():
+            assert torch.equal(v, ws[k]), k          # bit-exact integer bookkeeping
     scale = float(q_ref.abs().max())
     # same arithmetic up to the order of the fp32 sums of the recurrent product; h is rounded to bf16 every step
     assert float((q_res - q_ref).abs().max()) <= 1e-2 * scale
@@ -74,6 +82,8 @@ def test_resident_steps_full_width_and_repeatable():
     tok = _tokens(256, 14, 300, seed=9)
     q1, qt1, _, used = _encode(m, tok, True)
     assert used
+    q_steps, _, _, _ = _encode(m, tok, True, whole=False)      # the form that starts after the two tabulated steps
+    assert float((q_steps - q1).abs().max()) <= 1e-2 * float(q1.abs().max())      # (its first two steps: another kernel)
     q2, qt2, _, _ = _encode(m, tok, True)
     tok_b = _tokens(256, 14, 300, seed=10, full=True)      # every row runs all 14 steps
     qb, _, _, _ = _encode(m, tok_b, True)
@@ -94,8 +104,9 @@ def test_resident_entry_point_rejects_what_it_cannot_run():
     assert lib.vqa_lstm_resident_workgroups(2440) == 0 and lib.vqa_lstm_resident_workgroups(20) == 0
     x = torch.zeros(4096, dtype=torch.int64, device='cuda')
     p = x.data_ptr()
-    args = lambda H, B, t0, L: (p, H, p, 10, p, p, p, p, p, p, H, B, H, t0, L, p, p, None, 0, 0.0, p, None, None)
-    for bad in (args(2440, 8, 2, 5), args(48, 600, 2, 5), args(48, 8, 0, 5), args(44, 8, 2, 5)):
+    args = lambda H, B, t0, L, hh=None: (p, H, p, hh, 10, p, p, p, p, p, p, H, B, H, t0, L, p, p, None, 0, 0.0, p, None, None)
+    for bad in (args(2440, 8, 2, 5), args(48, 600, 2, 5), args(48, 8, 0, 5), args(44, 8, 2, 5), args(48, 8, 0, 1, p),
+                args(48, 8, 2, 65)):
         assert lib.vqa_lstm_resident(*bad) == -22
         assert b'vqa_lstm_resident' in lib.vqa_last_error_string()
 

@@ -22,13 +22,15 @@ lib.vqa_dev_resident_trace.argtypes = [ctypes.c_void_p]
 assert lib.vqa_dev_resident_trace(buf) == 0
 for wg in range(2):
     print('workgroup', 'first' if wg == 0 else 'middle')
-    base = buf[(wg * 16) * 12]
-    for st in range(12):
+    e = [buf[(wg * 16 + 15) * 12 + k] for k in range(4)]
+    print('  entry -> %.2f us -> sequences packed %.2f us -> steps 0/1 stored %.2f us (then the weight slice is requested)' % tuple(0.01 * (e[k + 1] - e[k]) for k in range(3)))
+    base = e[0]
+    for st in range(14):
         row = [buf[(wg * 16 + st) * 12 + k] for k in range(12)]
         if row[0] == 0:
             continue
         t0 = row[0]
-        txt = f'  step {st + 2:2d} starts {0.01 * (t0 - base):7.2f} us: barrier {0.01 * (row[1] - t0):6.2f}'
+        txt = f'  step {st:2d} starts {0.01 * (t0 - base):7.2f} us: barrier {0.01 * (row[1] - t0):6.2f}'
         prev = row[1]
         for ps in range(5):
             a, b = row[2 + 2 * ps], row[3 + 2 * ps]

@@ -39,7 +39,7 @@ _SIGNATURES = {
     'vqa_lstm_cell_packed_table': [_p, _i, _z, _p, _i, _i, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p, _u, _f, _p, _i, _p],
     'vqa_lstm_cell01_table': [_p, _i, _p, _i, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p, _u, _f, _i, _i, _p],
     'vqa_lstm_resident_workgroups': [_i],
-    'vqa_lstm_resident': [_p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _u, _f, _p, _p, _p],
+    'vqa_lstm_resident': [_p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _u, _f, _p, _p, _p],
     'vqa_lstm_cell_bwd_packed': [_p, _i, _z, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     'vqa_embedding_grad': [_p, _i, _z, _i, _p, _p, _p, _i, _p, _i, _i, _i, _p],
     'vqa_colsum_multi': [_p, _i, _p],

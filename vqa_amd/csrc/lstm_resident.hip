@@ -38,6 +38,7 @@ typedef unsigned long long u64;
 #ifndef RES_NBUF
 #define RES_NBUF 6                            // fragment buffers per wave: sub-steps s .. s + 5 requested or in use
 #endif
+#define RES_MAXL VQA_LSTM_RESIDENT_MAX_STEPS   // longest question
 #define RES_CELLS ((RES_RF * RES_NJ + 3) / 4) // (fragment, W fragment) pairs a wave updates per pass (the last wave may have fewer)
 
 static_assert(RES_NH * 4 == RES_NJ * 16, "a workgroup's gate rows are whole MFMA fragments");
@@ -134,9 +135,10 @@ __device__ __forceinline__ void product_pass(const bf16x8_t (&wf)[RES_KSUB][RES_
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 k_lstm_resident(const bf16_t* __restrict__ whh, int ldw, const bf16_t* __restrict__ xgu, int n_table,
                 const int64_t* __restrict__ tok, const float* __restrict__ c0, bf16_t* hring,
-                const int* __restrict__ len, float* __restrict__ q32, bf16_t* __restrict__ qT, int ld_q,
-                int B, int Bp, int H, int t_first, int L, const int* __restrict__ perm, const int* __restrict__ m_t,
-                bf16_t* __restrict__ q_drop, unsigned seed, unsigned thr, float dscale, u64* sync, int* status) {
+                int* len, float* __restrict__ q32, bf16_t* __restrict__ qT, int ld_q,
+                int B, int Bp, int H, int t_first, int L, int* perm, int* m_t,
+                bf16_t* __restrict__ q_drop, unsigned seed, unsigned thr, float dscale, u64* sync, int* status,
+                const float* __restrict__ hh_table) {
     extern __shared__ __align__(16) char smem[];
     f32x4* red = reinterpret_cast<f32x4*>(smem);                                   // [4 waves][RF * NJ][64 lanes]
     float* hst = reinterpret_cast<float*>(smem + 4 * RES_RF * RES_NJ * 64 * 16);   // [B][RES_NH] h of the running step
@@ -146,13 +148,172 @@ k_lstm_resident(const bf16_t* __restrict__ whh, int ldw, const bf16_t* __restric
     int* id_l = last_l + B;                                                        // [B] token id at the current step
     __shared__ int ok_s;
     __shared__ u64 epoch_s;
+    __shared__ int mt_l[RES_MAXL + 1];      // rows still running at step t
+    __shared__ int hist_l[RES_MAXL + 2];    // t_first == 0: rows with exactly n steps, then rows with more than n steps
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int nwg = gridDim.x;
     const int unit0 = blockIdx.x * RES_NH;
+    RES_STAMP(15, 0);
     const int kc0 = wave * (RES_KSUB * 4) + (lane >> 4);             // this lane's first 8-element chunk of K
 
-    // ---- the workgroup's slice of W_hh, once: fragment j, lane (m, kc): W row gate(m & 3) * H + unit0 + 4 j + (m >> 2)
+    // ring slots hold h as [K / 8 chunks][Bp rows][8] (Bp = VQA_LSTM_RESIDENT_RING_ROWS(B)): the 16 rows of a fragment are 256
+    // contiguous bytes per chunk, so a fragment load (lane = row, chunk) reads whole 128-byte lines (row-major rows
+    // cost one L1 tag lookup per lane: 4x the address-processing time)
+    const size_t slot_elems = (size_t)Bp * RES_PITCH;
+    const size_t sub_stride = (size_t)4 * Bp * 8;       // elements between sub-steps: four chunks
+    bool publish_pending = false;                       // a step's h has been stored and not yet met by a barrier
+    RES_STAMP(15, 1);
+    if (t_first > 0) {
+        // the caller packed the sequences and ran the steps before t_first
+        for (int b = tid; b < B; b += 256) {
+            const int ob = perm[b];
+            int last = len[ob] - 1;
+            if (last < 0) last += L;                    // all-pad row: index -1 selects the last step
+            ob_l[b] = ob;
+            last_l[b] = last;
+        }
+        for (int t = tid; t < L; t += 256) mt_l[t] = m_t[t];
+        for (int i = tid; i < B * RES_NH; i += 256) {
+            const int b = i / RES_NH, u = i % RES_NH;
+            cst[i] = unit0 + u < H ? c0[(size_t)b * H + unit0 + u] : 0.f;
+        }
+    } else {
+        // ---- the whole encoder in this launch.  Every workgroup packs the sequences for itself (the arithmetic of
+        // vqa_sequence_pack: lengths, rows sorted by descending step count, ties in row order), then runs steps 0 and 1
+        // of its hidden units from the two per-token tables (the arithmetic of vqa_lstm_cell01_table).
+        for (int n = tid; n <= L + 1; n += 256) hist_l[n] = 0;
+        __syncthreads();
+        bool bad = false;
+        for (int b = tid; b < B; b += 256) {
+            int z = 0;
+            for (int t0 = 0; t0 < L; t0 += 16) {        // 16 loads in flight (a plain loop waits for each one)
+                int64_t v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) v[u] = tok[(size_t)b * L + min(t0 + u, L - 1)];
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                    if (t0 + u < L) {
+                        z += v[u] == 0;
+                        bad |= v[u] < 0 || v[u] >= n_table;
+                    }
+            }
+            const int n = z == L ? L : L - z;           // an all-pad row takes all L steps
+            id_l[b] = n;
+            atomicAdd(&hist_l[n], 1);
+            if (blockIdx.x == 0 && len) len[b] = L - z;
+        }
+        if (bad && blockIdx.x == 0 && status) status[VQA_STATUS_BAD_TOKEN] = 1;
+        __syncthreads();
+        if (tid == 0) {                                 // hist_l[n] <- rows with more than n steps
+            int above = 0;
+            for (int n = L; n >= 0; --n) { const int here = hist_l[n]; hist_l[n] = above; above += here; }
+        }
+        __syncthreads();
+        for (int t = tid; t < L; t += 256) {
+            mt_l[t] = hist_l[t];
+            if (blockIdx.x == 0 && m_t) m_t[t] = hist_l[t];
+        }
+        for (int b = tid; b < B; b += 256) {
+            const int n = id_l[b];
+            int before = 0;
+            for (int o = 0; o < b; ++o) before += id_l[o] == n;
+            const int pos = hist_l[n] + before;
+            ob_l[pos] = b;
+            last_l[pos] = n - 1;
+            if (blockIdx.x == 0 && perm) perm[pos] = b;
+        }
+        __syncthreads();
+        RES_STAMP(15, 2);
+        const int rows1 = mt_l[1];
+        bf16_t* h1 = hring + slot_elems;                // published into slot 1: the first barrier flips to it
+        // three (row, four units) pieces per thread at a time: their token loads go out together, then their table
+        // gathers (a piece at a time would pay the two dependent memory round trips once per piece)
+        constexpr int PU = 3;
+        const int npiece = B * (RES_NH / 4);
+        for (int i0 = tid; i0 < npiece; i0 += 256 * PU) {
+            int row[PU], unit[PU], ob[PU];
+            bool live[PU], second[PU];
+            int64_t id0[PU], id1[PU];
+#pragma unroll
+            for (int u = 0; u < PU; ++u) {
+                const int i = min(i0 + 256 * u, npiece - 1);
+                row[u] = i / (RES_NH / 4);
+                unit[u] = unit0 + 4 * (i % (RES_NH / 4));
+                live[u] = i0 + 256 * u < npiece && unit[u] < H;
+                unit[u] = min(unit[u], H - 4);
+                ob[u] = ob_l[row[u]];
+                second[u] = row[u] < rows1;
+                id0[u] = tok[(size_t)ob[u] * L];
+                id1[u] = tok[(size_t)ob[u] * L + 1];
+            }
+            u16x8 a0[PU], b0[PU], a1[PU], b1[PU];
+            f32x4 hh[PU][4];
+#pragma unroll
+            for (int u = 0; u < PU; ++u) {
+                if (id0[u] < 0 || id0[u] >= n_table) id0[u] = 0;
+                if (id1[u] < 0 || id1[u] >= n_table) id1[u] = 0;
+                // a unit's four gates are adjacent in xgu: four units = 32 contiguous bytes
+                const u16x8* x0 = reinterpret_cast<const u16x8*>(xgu + ((size_t)id0[u] * H + unit[u]) * 4);
+                const u16x8* x1 = reinterpret_cast<const u16x8*>(xgu + ((size_t)id1[u] * H + unit[u]) * 4);
+                a0[u] = x0[0]; b0[u] = x0[1];
+                a1[u] = x1[0]; b1[u] = x1[1];
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    hh[u][g] = *reinterpret_cast<const f32x4*>(hh_table + (size_t)id0[u] * 4 * H + (size_t)g * H + unit[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < PU; ++u) {
+                if (!live[u]) continue;
+                const int last = last_l[row[u]];
+                f32x4 cn, hn;
+                auto emit = [&]() {                     // the row's question vector, when this step was its last
+                    const size_t o = (size_t)ob[u] * ld_q + unit[u];
+                    const u16x4 hb = u16x4{f32_to_bf16(hn[0]), f32_to_bf16(hn[1]), f32_to_bf16(hn[2]), f32_to_bf16(hn[3])};
+                    *reinterpret_cast<f32x4*>(q32 + o) = hn;
+                    *reinterpret_cast<u16x4*>(qT + o) = hb;
+                    if (q_drop) {
+                        u16x4 qd;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            qd[e] = f32_to_bf16(bf16_to_f32(hb[e]) * drop_mult(seed, (unsigned)(ob[u] * H + unit[u] + e), thr, dscale));
+                        *reinterpret_cast<u16x4*>(q_drop + o) = qd;
+                    }
+                };
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const u16x8& x = e < 2 ? a0[u] : b0[u];
+                    const int o4 = (e & 1) * 4;
+                    const float ig = fast_sigmoid(bf16_to_f32(x[o4])), fg = fast_sigmoid(bf16_to_f32(x[o4 + 1]));
+                    const float gg = fast_tanh(bf16_to_f32(x[o4 + 2])), og = fast_sigmoid(bf16_to_f32(x[o4 + 3]));
+                    cn[e] = fg * 0.f + ig * gg;         // (f * c_prev with c_prev = 0, as the one-step kernels compute it)
+                    hn[e] = og * fast_tanh(cn[e]);
+                }
+                if (last == 0) emit();
+                if (second[u]) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const u16x8& x = e < 2 ? a1[u] : b1[u];
+                        const int o4 = (e & 1) * 4;
+                        const float ig = fast_sigmoid(bf16_to_f32(x[o4]) + hh[u][0][e]), fg = fast_sigmoid(bf16_to_f32(x[o4 + 1]) + hh[u][1][e]);
+                        const float gg = fast_tanh(bf16_to_f32(x[o4 + 2]) + hh[u][2][e]), og = fast_sigmoid(bf16_to_f32(x[o4 + 3]) + hh[u][3][e]);
+                        cn[e] = fg * cn[e] + ig * gg;
+                        hn[e] = og * fast_tanh(cn[e]);
+                    }
+                    if (last == 1) emit();
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) cst[row[u] * RES_NH + (unit[u] - unit0) + e] = cn[e];
+                const u16x4 hb = u16x4{f32_to_bf16(hn[0]), f32_to_bf16(hn[1]), f32_to_bf16(hn[2]), f32_to_bf16(hn[3])};
+                u64* dst = reinterpret_cast<u64*>(h1 + ((size_t)(unit[u] >> 3) * Bp + row[u]) * 8 + (unit[u] & 4));
+                __hip_atomic_store(dst, __builtin_bit_cast(u64, hb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        publish_pending = true;
+        RES_STAMP(15, 3);
+    }
+    // ---- the workgroup's slice of W_hh, once (requested after the tabulated steps, whose loads it would otherwise queue
+    // behind, and landing while the first barrier is waited for): fragment j, lane (m, kc): W row gate(m & 3) * H + unit0 + 4 j + (m >> 2)
     bf16x8_t wf[RES_KSUB][RES_NJ];
     {
         const int m = lane & 15;
@@ -169,33 +330,18 @@ k_lstm_resident(const bf16_t* __restrict__ whh, int ldw, const bf16_t* __restric
             }
         }
     }
-    for (int b = tid; b < B; b += 256) {
-        const int ob = perm[b];
-        int last = len[ob] - 1;
-        if (last < 0) last += L;                        // all-pad row: index -1 selects the last step
-        ob_l[b] = ob;
-        last_l[b] = last;
-    }
-    for (int i = tid; i < B * RES_NH; i += 256) {
-        const int b = i / RES_NH, u = i % RES_NH;
-        cst[i] = unit0 + u < H ? c0[(size_t)b * H + unit0 + u] : 0.f;
-    }
     if (tid == 0) epoch_s = __hip_atomic_load(sync + SYNC_EPOCH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     const u64 epoch0 = epoch_s;
     u64 nbar = 0;
 
-    // ring slots hold h as [K / 8 chunks][Bp rows][8] (Bp = VQA_LSTM_RESIDENT_RING_ROWS(B)): the 16 rows of a fragment are 256
-    // contiguous bytes per chunk, so a fragment load (lane = row, chunk) reads whole 128-byte lines (row-major rows
-    // cost one L1 tag lookup per lane: 4x the address-processing time)
-    const size_t slot_elems = (size_t)Bp * RES_PITCH;
-    const size_t sub_stride = (size_t)4 * Bp * 8;       // elements between sub-steps: four chunks
     int slot = 0;
-    for (int t = t_first; t < L; ++t) {
-        const int rows = __builtin_amdgcn_readfirstlane(min(m_t[t], B));
+    bool ids_ready = false;
+    for (int t = t_first > 0 ? t_first : 2; t < L; ++t) {
+        const int rows = __builtin_amdgcn_readfirstlane(min(mt_l[t], B));
         if (rows <= 0) break;                            // (active[] never grows again: every workgroup leaves here)
         RES_STAMP(t - t_first, 0);
-        if (t > t_first) {
+        if (publish_pending) {
             ++nbar;
             if (!grid_barrier(sync, epoch0 + nbar, nwg, &ok_s)) {
                 if (blockIdx.x == 0 && tid == 0 && status) status[VQA_STATUS_RESIDENT_TIMEOUT] = 1;
@@ -206,12 +352,14 @@ k_lstm_resident(const bf16_t* __restrict__ whh, int ldw, const bf16_t* __restric
         RES_STAMP(t - t_first, 1);
         const bf16_t* hin = hring + (size_t)slot * slot_elems;
         bf16_t* hout = hring + (size_t)(slot ^ 1) * slot_elems;
-        for (int b = tid; b < rows; b += 256) {
-            int64_t id = tok[(size_t)ob_l[b] * L + t];
-            if (id < 0 || id >= n_table) id = 0;        // as the gather kernels: ids outside the table read the pad row
-            id_l[b] = (int)id;
+        if (!ids_ready) {                               // (later steps: fetched at the end of the step before)
+            for (int b = tid; b < rows; b += 256) {
+                int64_t id = tok[(size_t)ob_l[b] * L + t];
+                if (id < 0 || id >= n_table) id = 0;    // as the gather kernels: ids outside the table read the pad row
+                id_l[b] = (int)id;
+            }
+            __syncthreads();
         }
-        __syncthreads();
 
         const int nfrag = (rows + 15) >> 4;
         // The workgroups of an XCD (blockIdx.x % 8 under round-robin placement) start at different passes and wrap:
@@ -324,6 +472,17 @@ k_lstm_resident(const bf16_t* __restrict__ whh, int ldw, const bf16_t* __restric
                 }
             }
         }
+        // the next step's token ids, fetched under the stores and the barrier (every pass of this step is done with id_l)
+        if (t + 1 < L) {
+            const int rows_next = min(mt_l[t + 1], B);
+            for (int b = tid; b < rows_next; b += 256) {
+                int64_t id = tok[(size_t)ob_l[b] * L + t + 1];
+                if (id < 0 || id >= n_table) id = 0;
+                id_l[b] = (int)id;
+            }
+            ids_ready = true;                           // (published to the other waves by the barrier's __syncthreads)
+        }
+        publish_pending = true;
     }
     if (nbar != 0 && blockIdx.x == 0 && tid == 0)
         __hip_atomic_store(sync + SYNC_EPOCH, epoch0 + nbar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -340,20 +499,21 @@ int vqa_lstm_resident_workgroups(int H) {
     return (H + RES_NH - 1) / RES_NH;
 }
 
-int vqa_lstm_resident(const void* w_hh, int ld_w, const void* xg_table_u, int n_table_rows, const int64_t* tokens,
-                      const float* c, void* h_ring, const int32_t* lengths, float* q_f32, void* q_t, int ld_q,
-                      int B, int H, int t_first, int L, const int32_t* perm, const int32_t* active, void* q_drop,
+int vqa_lstm_resident(const void* w_hh, int ld_w, const void* xg_table_u, const float* hh_table, int n_table_rows,
+                      const int64_t* tokens, const float* c, void* h_ring, int32_t* lengths, float* q_f32, void* q_t, int ld_q,
+                      int B, int H, int t_first, int L, int32_t* perm, int32_t* active, void* q_drop,
                       unsigned drop_seed, float drop_p, uint64_t* sync_words, int32_t* status, hipStream_t stream) {
-    VQA_REQUIRE(w_hh && xg_table_u && tokens && c && h_ring && lengths && q_f32 && q_t && perm && active && sync_words,
-                "vqa_lstm_resident: null pointer");
+    VQA_REQUIRE(w_hh && xg_table_u && tokens && h_ring && q_f32 && q_t && sync_words, "vqa_lstm_resident: null pointer");
+    VQA_REQUIRE(t_first == 0 ? (hh_table != nullptr && L >= 2) : (c && lengths && perm && active),
+                "vqa_lstm_resident: t_first = 0 needs hh_table and L >= 2, t_first >= 1 needs c, lengths, perm and active");
     VQA_REQUIRE(H > 0 && H % 8 == 0 && H <= RES_PITCH, "vqa_lstm_resident: H must be a multiple of 8 and at most VQA_LSTM_RESIDENT_PITCH");
     VQA_REQUIRE(B >= 0 && B <= VQA_LSTM_RESIDENT_MAX_ROWS, "vqa_lstm_resident: B must be at most VQA_LSTM_RESIDENT_MAX_ROWS");
-    VQA_REQUIRE(t_first >= 1 && t_first <= L && n_table_rows > 0 && ld_w >= H && ld_w % 8 == 0 && ld_q >= H && ld_q % 4 == 0,
-                "vqa_lstm_resident: bad sizes");
+    VQA_REQUIRE(t_first >= 0 && t_first <= L && L <= RES_MAXL && n_table_rows > 0 && ld_w >= H && ld_w % 8 == 0 && ld_q >= H &&
+                ld_q % 4 == 0, "vqa_lstm_resident: bad sizes");
     VQA_REQUIRE((((uintptr_t)q_f32) & 15) == 0 && (((uintptr_t)q_t) & 7) == 0 && (((uintptr_t)q_drop) & 7) == 0,
                 "vqa_lstm_resident: q_f32 must be 16-byte aligned, q_t and q_drop 8-byte aligned");
-    VQA_REQUIRE((((uintptr_t)w_hh) & 15) == 0 && (((uintptr_t)h_ring) & 15) == 0 && (((uintptr_t)xg_table_u) & 7) == 0 &&
-                (((uintptr_t)sync_words) & 127) == 0, "vqa_lstm_resident: misaligned pointer");
+    VQA_REQUIRE((((uintptr_t)w_hh) & 15) == 0 && (((uintptr_t)h_ring) & 15) == 0 && (((uintptr_t)xg_table_u) & 15) == 0 &&
+                (((uintptr_t)hh_table) & 15) == 0 && (((uintptr_t)sync_words) & 127) == 0, "vqa_lstm_resident: misaligned pointer");
     VQA_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "vqa_lstm_resident: drop_p must be in [0, 1)");
     if (B == 0 || t_first == L) return 0;
     const int nwg = (H + RES_NH - 1) / RES_NH;
@@ -365,7 +525,8 @@ int vqa_lstm_resident(const void* w_hh, int ld_w, const void* xg_table_u, int n_
     const size_t lds = resident_lds_bytes(B);
     static bool attr_set[64] = {};
     if (dev < 64 && !attr_set[dev]) {
-        if (hipFuncSetAttribute((const void*)k_lstm_resident, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)k_lstm_resident, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)resident_lds_bytes(VQA_LSTM_RESIDENT_MAX_ROWS)) != hipSuccess)
             return vqa_set_error(-5, "vqa_lstm_resident: cannot raise the dynamic LDS limit");
         attr_set[dev] = true;
     }
@@ -374,7 +535,7 @@ int vqa_lstm_resident(const void* w_hh, int ld_w, const void* xg_table_u, int n_
     k_lstm_resident<<<nwg, 256, lds, stream>>>((const bf16_t*)w_hh, ld_w, (const bf16_t*)xg_table_u, n_table_rows, tokens, c,
                                                (bf16_t*)h_ring, lengths, q_f32, (bf16_t*)q_t, ld_q, B, VQA_LSTM_RESIDENT_RING_ROWS(B), H, t_first, L, perm,
                                                active, (bf16_t*)q_drop, drop_seed, thr, dsc,
-                                               reinterpret_cast<u64*>(sync_words), status);
+                                               reinterpret_cast<u64*>(sync_words), status, hh_table);
     return vqa_check_launch("vqa_lstm_resident");
 }
 

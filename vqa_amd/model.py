@@ -200,6 +200,7 @@ class _VQAHeadModel(nn.Module):
         self.fuse_first_two_cells = True   # steps 0 and 1 then run as one launch
         self.fold_embedding = True    # frozen encoder: embedding x first input projection tabulated per token id
         self.resident_encoder = True  # ... and steps 2.. of a single bf16 layer in one launch, W_hh resident in registers
+        self.resident_whole = True    # ... which then also packs the sequences and runs the two tabulated steps itself
         self._xg_table_u = self._resident_sync = None
         self.grad_ready_hook = None   # callable(bucket_index) fired as gradient buckets complete
         self.kernel_events = None     # set to {} to collect per-kernel HIP event pairs
@@ -644,6 +645,18 @@ class _VQAHeadModel(nn.Module):
         Ep, Hq, dt = _pad8(self.E), self.Hq, self.dt
         two = self.seq2vec.arch == '2-lstm'
         fuse_drop = q_drop is not None and not two     # (buffer, seed, p): the head's dropout of q written by the cell kernel
+        table = self._xg_table
+        Hh0 = self._enc_layers[0][1].shape[1]
+        if (self.resident_whole and self._xg_table_u is not None and self._hh_table is not None and 2 < L <= 64 and
+                B <= _lib.RESIDENT_MAX_ROWS and not (self.train_encoder and self._bptt)):
+            # the whole frozen encoder as ONE launch: packing, the two tabulated steps and the recurrent steps
+            if 'h_ring' not in ws:
+                ws['h_ring'] = torch.zeros((2, _lib.RESIDENT_PITCH // 8, _lib.resident_ring_rows(B), 8), dtype=self.compute_dtype, device=dev)
+            call('vqa_lstm_resident', ptr(self._enc_layers[0][1]), Hh0, ptr(self._xg_table_u), ptr(self._hh_table), table.shape[0],
+                 ptr(tokens), None, ptr(ws['h_ring']), ptr(ws['len']), ptr(ws['q32']), ptr(ws['qT']), Hq, B, Hh0, 0, L,
+                 ptr(ws['perm']), ptr(ws['m_t']), ptr(q_drop[0]) if fuse_drop else None, q_drop[1] if fuse_drop else 0,
+                 q_drop[2] if fuse_drop else 0.0, ptr(self._resident_sync), ptr(self._status_words(dev)))
+            return ws['q32']
         # packed sequences: rows sorted by length, so the rows still running at step t are the first
         # m_t[t] and their input projections are rows offs[t].. of xg; padding steps cost nothing
         call('vqa_sequence_pack', ptr(tokens), B, L, ptr(ws['len']), ptr(ws['perm']), ptr(ws['m_t']), ptr(ws['offs']),
@@ -679,7 +692,7 @@ class _VQAHeadModel(nn.Module):
                      q_drop[2] if fuse_drop else 0.0, _lib.resident_ring_rows(B) if resident else 0, dt)
                 t_first = 2
                 if resident:                             # steps 2 .. L-1 in one launch, W_hh resident in registers
-                    call('vqa_lstm_resident', ptr(whh), Hh, ptr(self._xg_table_u), table.shape[0], ptr(tokens),
+                    call('vqa_lstm_resident', ptr(whh), Hh, ptr(self._xg_table_u), None, table.shape[0], ptr(tokens),
                          ptr(ws['c']), ptr(ws['h_ring']), ptr(ws['len']), q32, qT, Hq, B, Hh, 2, L, ptr(ws['perm']),
                          ptr(ws['m_t']), ptr(q_drop[0]) if fuse_drop else None, q_drop[1] if fuse_drop else 0,
                          q_drop[2] if fuse_drop else 0.0, ptr(self._resident_sync), ptr(self._status_words(dev)))
