@@ -151,3 +151,12 @@ def test_resident_handoff_is_repeatable_under_load():
                 assert torch.equal(q, first), (load, i)
     torch.cuda.synchronize()
     m.check_status()
+
+
+@pytest.mark.parametrize('B,L', [(600, 6), (9, 70)])
+def test_shapes_beyond_the_resident_limits_use_the_per_step_kernels(B, L):
+    m, po = _model(48)
+    tok = _tokens(B, L, 60, seed=B + L)
+    q, _, _, _ = _encode(m, tok, True)
+    ref = vqa_ref.encode_question(tok, po)
+    assert float((q.cpu() - ref).abs().max()) <= 2e-2 * float(ref.abs().max())

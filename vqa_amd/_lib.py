@@ -14,7 +14,7 @@ import torch
 F32, BF16 = 0, 1
 ABI_VERSION = 220          # VQA_HIP_VERSION of include/vqa_hip.h these signatures were written against
 STATUS_WORDS = 4           # VQA_STATUS_BAD_TOKEN, VQA_STATUS_BAD_TARGET, VQA_STATUS_SKIPPED_STEP, VQA_STATUS_RESIDENT_TIMEOUT
-RESIDENT_PITCH, RESIDENT_MAX_ROWS, RESIDENT_SYNC_WORDS = 2432, 512, 176     # VQA_LSTM_RESIDENT_* of the header
+RESIDENT_PITCH, RESIDENT_MAX_ROWS, RESIDENT_SYNC_WORDS, RESIDENT_MAX_STEPS = 2432, 512, 176, 64     # VQA_LSTM_RESIDENT_* of the header
 
 
 def resident_ring_rows(B: int) -> int:

@@ -21,6 +21,7 @@
 // not complete sets an abort word, every workgroup leaves and the status word tells the host.
 #include "common.h"
 #include "vqa_hip.h"
+#include <mutex>
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
@@ -520,15 +521,23 @@ int vqa_lstm_resident(const void* w_hh, int ld_w, const void* xg_table_u, const 
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
         return vqa_set_error(-5, "vqa_lstm_resident: cannot query the device");
+    if (stream) {      // the compute-unit count and the kernel attribute are the current device's: the stream must be on it
+        hipDevice_t sdev = -1;
+        if (hipStreamGetDevice(stream, &sdev) != hipSuccess || (int)sdev != dev)
+            return vqa_set_error(-22, "vqa_lstm_resident: `stream` does not belong to the current device");
+    }
     // every workgroup takes a whole CU's registers, and all of them have to be resident for the grid barrier
     VQA_REQUIRE(nwg <= cus, "vqa_lstm_resident: more workgroups than compute units (use the per-step entry points)");
     const size_t lds = resident_lds_bytes(B);
+    static std::mutex attr_mutex;
     static bool attr_set[64] = {};
-    if (dev < 64 && !attr_set[dev]) {
+    std::lock_guard<std::mutex> lock(attr_mutex);           // (a launch is a few microseconds; host threads take turns)
+    const bool tracked = dev >= 0 && dev < 64;
+    if (!tracked || !attr_set[dev]) {
         if (hipFuncSetAttribute((const void*)k_lstm_resident, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)resident_lds_bytes(VQA_LSTM_RESIDENT_MAX_ROWS)) != hipSuccess)
             return vqa_set_error(-5, "vqa_lstm_resident: cannot raise the dynamic LDS limit");
-        attr_set[dev] = true;
+        if (tracked) attr_set[dev] = true;
     }
     const unsigned thr = drop_threshold(drop_p);
     const float dsc = 1.0f / (1.0f - drop_p);

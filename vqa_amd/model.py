@@ -647,7 +647,7 @@ class _VQAHeadModel(nn.Module):
         fuse_drop = q_drop is not None and not two     # (buffer, seed, p): the head's dropout of q written by the cell kernel
         table = self._xg_table
         Hh0 = self._enc_layers[0][1].shape[1]
-        if (self.resident_whole and self._xg_table_u is not None and self._hh_table is not None and 2 < L <= 64 and
+        if (self.resident_whole and self._xg_table_u is not None and self._hh_table is not None and 2 < L <= _lib.RESIDENT_MAX_STEPS and
                 B <= _lib.RESIDENT_MAX_ROWS and not (self.train_encoder and self._bptt)):
             # the whole frozen encoder as ONE launch: packing, the two tabulated steps and the recurrent steps
             if 'h_ring' not in ws:
@@ -682,7 +682,7 @@ class _VQAHeadModel(nn.Module):
             qT = ws['qT'].data_ptr() + esz * li * Hh
             t_first = 0
             if from_table and self._hh_table is not None and L >= 2 and self.fuse_first_two_cells:   # no GEMM between them
-                resident = (self._xg_table_u is not None and hs is None and L > 2 and B <= _lib.RESIDENT_MAX_ROWS)
+                resident = (self._xg_table_u is not None and hs is None and 2 < L <= _lib.RESIDENT_MAX_STEPS and B <= _lib.RESIDENT_MAX_ROWS)
                 if resident and 'h_ring' not in ws:      # two slots of h, chunk-major, K padded with zeros to the kernel's contraction length
                     ws['h_ring'] = torch.zeros((2, _lib.RESIDENT_PITCH // 8, _lib.resident_ring_rows(B), 8), dtype=self.compute_dtype, device=dev)
                 call('vqa_lstm_cell01_table', ptr(table), 4 * Hh, ptr(self._hh_table), table.shape[0], ptr(tokens),
