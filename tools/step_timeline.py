@@ -1,10 +1,12 @@
-"""Prints the kernel timeline of the last full train step found in a rocprofv3 kernel trace (csv)."""
+"""Prints the kernel timeline of the median-length train step found in a rocprofv3 kernel trace (csv)."""
 import csv, glob, sys, os
 d = sys.argv[1]
 f = max(glob.glob(os.path.join(d, '**', '*kernel_trace.csv'), recursive=True), key=os.path.getmtime)   # newest run
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
-marks = [i for i, r in enumerate(rows) if 'k_sequence_pack' in r['Kernel_Name']]
-a, b = marks[-2], marks[-1]
+marks = [i for i, r in enumerate(rows) if i > 0 and 'k_adam' in rows[i - 1]['Kernel_Name']]     # a step ends with the Adam update
+# the step of median length (the last one of a run ends at a host synchronisation: its successor starts late)
+spans = sorted((int(rows[b]['Start_Timestamp']) - int(rows[a]['Start_Timestamp']), a, b) for a, b in zip(marks[:-1], marks[1:]))
+_, a, b = spans[len(spans) // 2]
 t0 = int(rows[a]['Start_Timestamp'])
 busy = 0
 for r in rows[a:b]:
