@@ -1,4 +1,4 @@
-# same-box A/B of bench.py configurations: each line of stdin is "<label>|<env assignments>|<bench flags>"; two rounds
+# same-box A/B of bench.py configurations: bash tools/ab_step.sh <file>; each line of the file is "<label>|<env assignments>|<bench flags>" (example: tools/ab_encoder.txt); two rounds
 cd $GRAFT_REPO_ROOT
 for round in 1 2; do
   while IFS='|' read -r label envs flags; do
