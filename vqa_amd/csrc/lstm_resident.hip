@@ -1,4 +1,5 @@
-// Weight-stationary recurrent steps of a frozen LSTM layer: ALL remaining time steps in one launch (gfx950).
+// Weight-stationary question encoder: the recurrent steps of a frozen LSTM layer -- or the whole encoder, sequence
+// packing and the two tabulated steps included -- in ONE launch (gfx950).
 //
 // The per-step form (vqa_gemm_slabs + vqa_lstm_cell_packed_table) streams the 46 MB of W_hh through every CU
 // once per step and pays two dependent launches per step.  Here W_hh is loaded ONCE, into registers: the chip
@@ -10,15 +11,16 @@
 //                                                             lane ends up with the four gates (i, f, g, o) of ONE
 //                                                             (batch row, hidden unit) in one accumulator
 //   sum of the four K quarters through LDS (fixed order), + the tabulated input projection, cell update with the
-//   cell state resident in LDS, h_t's 12 columns written to the other slot of a two-slot ring in global memory,
-//   q for the rows whose last token this was;
+//   cell state resident in LDS, h_t's 12 columns written to the other slot of a two-slot ring in global memory
+//   (8-byte write-through stores after the step's last pass), q for the rows whose last token this was;
 //   grid barrier (every workgroup needs all of h_t for the next step).
 //
 // Only the live rows of a step (sequences are sorted by length: the first active[t]) are read, multiplied or
-// updated, in passes of 64 rows.  The grid barrier is a two-level counter (8 group counters + 1 top counter, 64-bit,
-// monotonic across launches); the grid is at most one workgroup per CU and every wave needs a whole SIMD's
-// registers, so all workgroups are resident together.  Spins are bounded by the wall clock: a barrier that does
-// not complete sets an abort word, every workgroup leaves and the status word tells the host.
+// updated, in passes of 64 rows.  The grid barrier is eight arrival counters (64-bit, monotonic across launches, one
+// per value of blockIdx.x % 8) polled by one wave, then one agent-scope acquire; the grid is at most one workgroup
+// per CU and every wave needs a whole SIMD's registers, so all workgroups are resident together.  Spins are bounded
+// by the wall clock: a barrier that does not complete sets an abort word, every workgroup leaves and the status word
+// tells the host.
 #include "common.h"
 #include "vqa_hip.h"
 #include <mutex>
