@@ -160,3 +160,30 @@ def test_shapes_beyond_the_resident_limits_use_the_per_step_kernels(B, L):
     q, _, _, _ = _encode(m, tok, True)
     ref = vqa_ref.encode_question(tok, po)
     assert float((q.cpu() - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
+
+
+def test_train_steps_agree_between_the_encoder_forms():
+    """Three fused train steps (dropout on) with the one-launch encoder, with the three-launch form and with the
+    per-step kernels: the same losses up to the bf16 noise of the question vector, and the same loss as the oracle."""
+    from vqa_amd.model import VQAAttnModel
+    kw = dict(vq=60, C=13, E=24, Hq=104, Dv=64, A=24, F=40, Hf=16)
+    p = vqa_ref.init_params(seed=8, **kw)
+    b = vqa_ref.synthetic_batch(37, 9, kw['Dv'], 11, kw['vq'], kw['C'], seed=5)
+    feats = b['feats'].to(torch.bfloat16)
+    losses = {}
+    for form in ('whole', 'steps', 'per-step'):
+        m = VQAAttnModel(['w'] * kw['vq'], ['a'] * kw['C'], None, dtype=torch.bfloat16, emb_size=kw['E'], question_out=kw['Hq'],
+                         visual_out=kw['Dv'], attention_dim=kw['A'], fusion_in=kw['F'], fusion_hidden=kw['Hf'], seed=3)
+        m.load_state_dict(p)
+        m = m.to('cuda').train()
+        m.resident_encoder, m.resident_whole = form != 'per-step', form == 'whole'
+        losses[form] = [float(m.train_step(feats.cuda(), b['tokens'].cuda(), b['answers'].cuda(), lr=1e-3)) for _ in range(3)]
+        m.sync()
+        assert (m._xg_table_u is not None) == (form != 'per-step')
+    for form in ('whole', 'steps'):
+        for got, want in zip(losses[form], losses['per-step']):
+            assert abs(got - want) <= 1e-2 * abs(want), (form, losses)
+    po = {k: v.to(torch.bfloat16).float() for k, v in p.items()}
+    seeds = [vqa_ref.site_seed(3, 1, s) for s in range(4)]
+    _, loss_ref, _ = vqa_ref.loss_and_grads(po, feats.float(), b['tokens'], b['answers'], None, 1, drop_seeds=seeds)
+    assert abs(losses['whole'][0] - float(loss_ref)) <= 1e-2 * float(loss_ref)
