@@ -199,6 +199,7 @@ class _VQAHeadModel(nn.Module):
         self.fold_first_step = True   # ... and the first recurrent product (h_0 depends on one token)
         self.fuse_first_two_cells = True   # steps 0 and 1 then run as one launch
         self.fold_embedding = True    # frozen encoder: embedding x first input projection tabulated per token id
+        self.collective_cus = 0       # compute units a gradient collective's kernel may hold beside backward (train_step sets it)
         self.resident_encoder = True  # ... and steps 2.. of a single bf16 layer in one launch, W_hh resident in registers
         self.resident_whole = True    # ... which then also packs the sequences and runs the two tabulated steps itself
         self._xg_table_u = self._resident_sync = None
@@ -440,10 +441,12 @@ class _VQAHeadModel(nn.Module):
         return self._slab
 
     # ------------------------------------------------------------------ kernel helpers
-    def _gemm_slabs(self, A, lda, akm, Bm, ldb, bkm, M, N, K, active_rows=None, active_k=None):
+    def _gemm_slabs(self, A, lda, akm, Bm, ldb, bkm, M, N, K, active_rows=None, active_k=None, sk_max=None):
         """fp32 partial sums of A B^T into the slab workspace -> (slab tensor, nslab, stride).
         active_rows: device address of an int32 row count past which output tiles are skipped."""
         sk = call('vqa_gemm_splitk_hint', M, N, K, akm, bkm)
+        if sk_max is not None:
+            sk = max(1, min(sk, sk_max))
         stride = M * N
         slab = self._slabs(sk * stride, A.device)
         call('vqa_gemm_slabs_rows', ptr(A), lda, akm, ptr(Bm), ldb, bkm, ptr(slab), stride, N, M, N, K, sk,
@@ -470,7 +473,14 @@ class _VQAHeadModel(nn.Module):
         swapped: the product runs as x^T dy (N x M) and the split-K reduction transposes it back."""
         if swapped:
             ev = self._event_pair('wgrad:' + wname)
-            slab, sk, stride = self._gemm_slabs(x, ldx, 0, dy, ld_dy, 0, N, M, K, active_k=active_k)
+            # every workgroup of this product runs for the whole launch, one per CU: while a collective's kernel holds
+            # compute units (collective_cus, set by train_step), one workgroup too many would wait for a second round
+            # and double the launch, so the K ranges are cut to what fits beside it (6 -> 5 ranges: +3 %)
+            sk_max = None
+            if self.collective_cus:
+                cus = torch.cuda.get_device_properties(x.device).multi_processor_count
+                sk_max = max(1, (cus - self.collective_cus) // (((N + 255) // 256) * ((M + 255) // 256)))
+            slab, sk, stride = self._gemm_slabs(x, ldx, 0, dy, ld_dy, 0, N, M, K, active_k=active_k, sk_max=sk_max)
             if ev is not None:
                 ev[1].record()
             call('vqa_slab_sum_transpose', ptr(slab), sk, stride, N, M, ptr(self._g(wname)), N)
@@ -1044,6 +1054,7 @@ class _VQAHeadModel(nn.Module):
             self._bptt = True
             self._forward_impl(feats, tokens, captions)
             loss = self.loss_and_grad_logits(answers, reduce=False)
+            self.collective_cus = getattr(reducer, 'collective_cus', 0) if (reducer is not None and reducer.enabled) else 0
             if reducer is not None:
                 reducer.begin(self)
                 self.grad_ready_hook = reducer.bucket_ready

@@ -39,6 +39,10 @@ class GradReducer:
         can be deferred.  `force` issues the collectives even in a group of one rank (where they are the
         identity): a single-GPU machine can then exercise the RCCL stream ordering of the bucketed path."""
         self.group = process_group
+        # compute units the collectives' kernels may hold while backward is still running (one per RCCL channel: the
+        # cap of reserve_compute_units_for_resident_kernels, plus a margin): kernels whose workgroups all have to
+        # be resident at once (the big weight gradient, the weight-stationary encoder) are sized to fit beside them
+        self.collective_cus = 56
         # the last bucket (the image projection) only completes at the very end of backward: its
         # all-reduce is left running under the next step's parameter-independent prologue
         self.defer_last = defer_last
