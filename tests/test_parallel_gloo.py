@@ -66,6 +66,19 @@ def _worker(rank, world, port, out_dir):
     red0.finish()
     assert red0.launched == list(fm3.buckets)
     assert torch.equal(fm3._flat_grad, fm._flat_grad)
+    # a model with several attention hops: everything but the last bucket goes out as one collective even with a
+    # small byte threshold (nothing is launched while backward still has its big one-workgroup-per-sample kernels ahead)
+    fm4 = _FakeModel(g, order, cuts=[4, 8, len(order) - 1])
+    fm4.hops = 2
+    red1 = GradReducer(bucket_bytes=1)
+    red1.begin(fm4)
+    for i in range(len(fm4.buckets)):
+        red1.bucket_ready(i)
+        if i < len(fm4.buckets) - 2:
+            assert red1.launched == []
+    red1.finish()
+    assert red1.launched == [(fm4.buckets[0][0], fm4.buckets[-2][1]), fm4.buckets[-1]]
+    assert torch.equal(fm4._flat_grad, fm._flat_grad)
     # accuracy counters: integer sums
     logits = vqa_ref.forward(p, full['feats'][sl], full['tokens'][sl])
     pred = vqa_ref.argmax_first(logits.numpy())

@@ -60,6 +60,7 @@ class GradReducer:
         self._flat_grad: Optional[torch.Tensor] = None
         self._buckets: Sequence[Tuple[int, int]] = ()
         self._fired: List[bool] = []
+        self._hold_all = False
         self._next = 0                      # first bucket not yet handed to a collective or to the pending run
         self._run: Optional[Tuple[int, int]] = None   # element range of the completed buckets being held back
         self.launched: List[Tuple[int, int]] = []     # element ranges of the collectives of this pass, in order
@@ -84,6 +85,11 @@ class GradReducer:
         self.launched = []
         self._pass += 1
         self._timed = self.timing is not None and self._pass % max(int(self.timing_stride), 1) == 0
+        # With several attention hops backward still has whole-CU kernels with more workgroups than compute units to
+        # launch (the earlier hops' attention backward: one workgroup per sample) after the first buckets complete, and
+        # beside a collective's kernel they would need an extra round: everything but the last bucket then goes out as
+        # one collective once the bucket before the last is complete (the last hop's small terms).
+        self._hold_all = getattr(model, 'hops', 1) > 1
 
     def _launch(self, s: int, e: int):
         self.launched.append((s, e))
@@ -113,7 +119,7 @@ class GradReducer:
                 self._last_handle = self._launch(s, e)
                 continue
             self._run = (self._run[0], e) if self._run is not None else (s, e)
-            if 4 * (self._run[1] - self._run[0]) >= self.bucket_bytes or i >= n - 2:
+            if (not self._hold_all and 4 * (self._run[1] - self._run[0]) >= self.bucket_bytes) or i >= n - 2:
                 self._handles.append(self._launch(*self._run))
                 self._run = None
 
