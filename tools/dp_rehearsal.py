@@ -71,7 +71,7 @@ def run(reducer_on, collective_cus, steps=150):
 
 base = run(False, 0)
 print(f'no reducer: {base:.1f} us per step', flush=True)
-for cus in (32, 48):
+for cus in [int(a) for a in sys.argv[1:]] or [32, 48]:
     for busbw in (150.0, 250.0, 350.0):
         cfg.update(cus=cus, busbw=busbw)
         t5 = run(True, 56)
