@@ -89,6 +89,27 @@ def test_fused_epilogue(engine, out_dtype):
             assert float(C[:, N:].abs().max() if ldc > N else 0.0) == 0.0      # padding untouched
 
 
+@pytest.mark.parametrize('engine', [0, 10, 11])
+@pytest.mark.parametrize('out_dtype', [torch.bfloat16, torch.float32])
+def test_streaming_stores_large_output(engine, out_dtype):
+    """An output larger than the Infinity Cache (256 MB) with 128-byte-aligned rows is written with streaming stores (a
+    kernel instance of its own in the 256 x 256 engines)."""
+    M, N, K = 106000, 1280, 192
+    As, lda, Bs, ldb, ref = make(M, N, K, 1, 1, torch.bfloat16, 21)
+    g = torch.Generator(device='cuda').manual_seed(4)
+    bias = torch.randn(N, device='cuda', generator=g)
+    rs = torch.rand(M, device='cuda', generator=g) * 0.2
+    C = torch.zeros(M, N, device='cuda', dtype=out_dtype)
+    assert C.numel() * C.element_size() >= 256 << 20 and C.data_ptr() % 128 == 0
+    call('vqa_gemm_fused', ptr(As), lda, 1, ptr(Bs), ldb, 1, ptr(C), N, M, N, K, ptr(bias), ptr(rs), 0,
+         BF16 if out_dtype == torch.bfloat16 else F32, BF16, engine)
+    torch.cuda.synchronize()
+    want = ref * rs.double()[:, None] + bias.double()[None, :]
+    tol = 1e-2 if out_dtype == torch.bfloat16 else 3e-5
+    err = float((C.double() - want).abs().max() / want.abs().max())
+    assert err <= tol, (engine, out_dtype, err)
+
+
 def test_fp32_gemm():
     for akm, bkm in ((1, 1), (1, 0), (0, 0)):
         As, lda, Bs, ldb, ref = make(77, 45, 131, akm, bkm, torch.float32, 5)

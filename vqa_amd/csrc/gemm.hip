@@ -1344,7 +1344,10 @@ static inline int pick_tile(int M, int N, int K, int akm, int bkm, int engine) {
     return (M > 64 && N > 64 && t128 >= 40) ? TILE_128 : TILE_64;
 }
 
-// Streaming (non-temporal) output stores pay when the output is large and every row starts on a 128-byte line.
+// Streaming (non-temporal) output stores when the output is larger than the 256 MB Infinity Cache and every row starts
+// on a 128-byte line.  A smaller output is stored through the caches: its consumer finds it there, and inside the
+// train step the 120 MB projection output written this way costs the launch 4-5 us less than streamed past the caches
+// (as a stand-alone loop, where the previous call's output still fills the cache, streaming is 1-3 % faster).
 static inline int want_nt_store(const Epi& epi, int M, int N, int splitk) {
 #ifdef VQA_DEV
     static const int forced = [] { const char* e = getenv("VQA_GEMM_NT"); return e ? atoi(e) : -1; }();
@@ -1355,7 +1358,7 @@ static inline int want_nt_store(const Epi& epi, int M, int N, int splitk) {
     const bool aligned = (((size_t)epi.ld * esz) % 128 == 0) && (((uintptr_t)epi.out) % 128 == 0) && ((epi.split_stride * 4) % 128 == 0);
     if (!aligned) return 0;
     if (forced >= 0) return forced;
-    return (size_t)M * N * esz * splitk >= ((size_t)96 << 20);
+    return (size_t)M * N * esz * splitk >= ((size_t)256 << 20);
 }
 
 // The eight-phase kernel is the default 256 x 256 engine (development builds: VQA_GEMM_PP=0 keeps the ring kernels)
