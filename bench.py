@@ -115,6 +115,9 @@ def main():
         dist.init_process_group('nccl', device_id=dev)
     elif args.rccl_single:
         dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29533', rank=0, world_size=1, device_id=dev)
+    if world > 1 or args.rccl_single:
+        from vqa_amd.parallel import connect_collectives
+        connect_collectives(dev)       # RCCL's peer connections are made here, not inside the first steps
 
     from vqa_amd.model import VQAAttnModel
     from vqa_amd.parallel import GradReducer

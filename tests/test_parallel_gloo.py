@@ -28,7 +28,8 @@ def _worker(rank, world, port, out_dir):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
-    from vqa_amd.parallel import GradReducer, reduce_counters
+    from vqa_amd.parallel import GradReducer, connect_collectives, reduce_counters
+    connect_collectives('cpu', nbytes=4096)      # the warm-up collectives every rank issues after joining the group
     p = vqa_ref.init_params(seed=0, **KW)
     full = vqa_ref.synthetic_batch(8, 9, KW['Dv'], 7, KW['vq'], KW['C'], seed=4)
     sl = slice(rank * 4, rank * 4 + 4)

@@ -30,6 +30,21 @@ def reserve_compute_units_for_resident_kernels(max_channels: int = 48) -> None:
     os.environ.setdefault('NCCL_MAX_NCHANNELS', str(int(max_channels)))
 
 
+def connect_collectives(device, process_group=None, nbytes: int = 32 << 20) -> None:
+    """Call once AFTER ``init_process_group`` and before the first train step.  RCCL connects its peers (rings, channels,
+    the protocol for large messages) inside the first collective of each kind, which can take seconds and holds compute
+    units meanwhile; doing that here, with one bucket-sized and one small all-reduce followed by a device
+    synchronise, keeps it out of the step -- where the weight-stationary encoder would otherwise wait at its first
+    grid barrier for the compute units the connecting collective holds."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    for n in (max(int(nbytes) // 4, 1), 1):
+        t = torch.zeros(n, device=device, dtype=torch.float32)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=process_group)
+    if torch.device(device).type == 'cuda':
+        torch.cuda.synchronize(device)
+
+
 class GradReducer:
     def __init__(self, process_group: Optional["dist.ProcessGroup"] = None, defer_last: bool = True,
                  force: bool = False, bucket_bytes: int = 32 << 20, defer_all: bool = True):

@@ -247,9 +247,10 @@ def init_distributed(args):
     torch.cuda.set_device(dev)
     started = launched and not _dist_on()
     if started:
-        from .parallel import reserve_compute_units_for_resident_kernels
+        from .parallel import connect_collectives, reserve_compute_units_for_resident_kernels
         reserve_compute_units_for_resident_kernels()
         dist.init_process_group('nccl', device_id=dev)
+        connect_collectives(dev)
     return rank, world, dev, started
 
 
