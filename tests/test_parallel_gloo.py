@@ -96,3 +96,17 @@ def test_two_rank_gradient_allreduce_and_counters(tmp_path):
     port = 29500 + (os.getpid() % 2000)
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert os.path.exists(tmp_path / 'ok0') and os.path.exists(tmp_path / 'ok1')
+
+
+def test_collective_cus_follow_the_channel_cap(monkeypatch):
+    """The compute units left to the collectives' kernels = RCCL's channel cap + a margin of 8: the drivers' cap of 48 by
+    default, the user's NCCL_MAX_NCHANNELS when set, at most half of the chip."""
+    from vqa_amd.parallel import GradReducer, reserve_compute_units_for_resident_kernels
+    monkeypatch.delenv('NCCL_MAX_NCHANNELS', raising=False)
+    assert GradReducer().collective_cus == 56
+    monkeypatch.setenv('NCCL_MAX_NCHANNELS', '32')
+    reserve_compute_units_for_resident_kernels()             # a user's setting wins
+    assert os.environ['NCCL_MAX_NCHANNELS'] == '32'
+    assert GradReducer().collective_cus == 40
+    monkeypatch.setenv('NCCL_MAX_NCHANNELS', '200')
+    assert GradReducer().collective_cus == 128

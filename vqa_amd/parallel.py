@@ -55,9 +55,12 @@ class GradReducer:
         identity): a single-GPU machine can then exercise the RCCL stream ordering of the bucketed path."""
         self.group = process_group
         # compute units the collectives' kernels may hold while backward is still running (one per RCCL channel: the
-        # cap of reserve_compute_units_for_resident_kernels, plus a margin): kernels whose workgroups all have to
-        # be resident at once (the big weight gradient, the weight-stationary encoder) are sized to fit beside them
-        self.collective_cus = 56
+        # cap of reserve_compute_units_for_resident_kernels or the user's own NCCL_MAX_NCHANNELS, plus a margin):
+        # kernels whose workgroups all have to be resident at once (the big weight gradient, the weight-stationary
+        # encoder) are sized to fit beside them
+        import os
+        channels = os.environ.get('NCCL_MAX_NCHANNELS', '')
+        self.collective_cus = min((int(channels) if channels.isdigit() else 48) + 8, 128)
         # the last bucket (the image projection) only completes at the very end of backward: its
         # all-reduce is left running under the next step's parameter-independent prologue
         self.defer_last = defer_last
